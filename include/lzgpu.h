@@ -1,0 +1,212 @@
+/* lzgpu.h -- C ABI of the MI355X (gfx950) drop-in for LASTZ's seed -> HSP -> gapped hot path.
+ *
+ * The reference (lastz 1.04.58) has no plugin API; the boundary for this path is three ordinary
+ * C functions called from src/lastz.c (and src/tweener.c).  Each entry point below names the
+ * reference interface it replaces; INTEGRATION.md shows the ~40-line overlay that binds the
+ * reference's structs (seq, seed, postable, hitprocinfo, segtable, alignel) to these PODs.
+ *
+ *   B1  build_seed_position_table   src/pos_table.h:230-232   (callers src/lastz.c:1205,1211,1302)
+ *   B2  seed_hit_search             src/seed_search.h:265-276 (caller  src/lastz.c:3112)
+ *   B3  reduce_to_points + gapped_extend  src/gapped_extend.h:151-159 (callers src/lastz.c:3401,3419)
+ *
+ * Conventions (reference default build): positions are u32 (unspos), scores s32, sequences are
+ * one ASCII byte per base.  All functions are called from one host thread (the reference is
+ * single-threaded and non-reentrant, src/seed_search.c:364-365).
+ *
+ * Return codes, every int-returning entry point:
+ *     0   done, results are complete and bit-identical to the reference's
+ *    >0   not handled (an LZGPU_NH_* reason): nothing was produced; the caller runs the
+ *         reference CPU routine instead (never partial results)
+ *    <0   fatal (HIP error / out of memory); the reference-side binding calls suicidef()
+ *         (src/utilities.c:1866-1884), matching the reference's "errors are fatal" behaviour
+ * There is NO CPU fallback inside this library: without a usable gfx950 device every entry
+ * point fails with LZGPU_ERR_NO_DEVICE.
+ */
+#ifndef LZGPU_H
+#define LZGPU_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZGPU_MAX_PARTS   16
+#define LZGPU_MAX_PROBES  128
+
+#define LZGPU_ERR_NO_DEVICE   (-1)
+#define LZGPU_ERR_HIP         (-2)
+#define LZGPU_ERR_OOM         (-3)
+#define LZGPU_ERR_ARG         (-4)
+#define LZGPU_ERR_STATE       (-5)
+
+#define LZGPU_NH_SEED          1   /* seed not strict / too heavy (half-weight, resolving, >28 bits) */
+#define LZGPU_NH_SCORE_CLASSES 2   /* score matrix needs more than 32 row or column classes        */
+#define LZGPU_NH_HITS_OVERFLOW 3   /* one query position has more raw hits than the chunk capacity */
+#define LZGPU_NH_HSP_OVERFLOW  4   /* more candidate HSPs than the output capacity                 */
+#define LZGPU_NH_SIZE          5   /* sequence >= 2^31 bases                                        */
+#define LZGPU_NH_IDENTICAL     6   /* identical sequences (trivial self-alignment path)            */
+#define LZGPU_NH_UNSUPPORTED   7   /* option outside the fast-path predicate  */
+
+/* Output of the reference's seed parser (struct seed, src/seeds.h:37-76) for a strict seed:
+ * packed = OR_i ((w >> shift[i]) & mask[i]) (apply_seed, src/seeds.c:1335-1378), plus the XOR
+ * masks to probe, in the reference's probe order (src/seed_search.c:522-549): probe 0 is the
+ * exact word (xor 0), then the transition flips (and flip pairs for withTrans==2). */
+typedef struct lz_seed_desc {
+    int32_t  length;                       /* seed->length  (bases)                 */
+    int32_t  weight_bits;                  /* seed->weight  (bits, 2 per match)     */
+    int32_t  num_parts;                    /* seed->numParts                        */
+    int32_t  shift[LZGPU_MAX_PARTS];       /* seed->shift[]                         */
+    uint32_t mask[LZGPU_MAX_PARTS];        /* seed->mask[]                          */
+    int32_t  num_probes;
+    uint32_t probe_xor[LZGPU_MAX_PROBES];
+} lz_seed_desc;
+
+/* Convenience for callers without the reference's parser: compile a strict seed pattern
+ * ('1' match, '0'/'X'/'x' don't care) exactly as src/seeds.c:321-640 does, with_trans in {0,1,2}
+ * as set by --transition / --notransition / --twins (src/lastz.c).  Returns 0 or LZGPU_NH_SEED. */
+int lzgpu_seed_from_pattern(const char* pattern, int with_trans, lz_seed_desc* out);
+
+/* 0 if a gfx950 device is usable by this process, else LZGPU_ERR_NO_DEVICE. */
+int lzgpu_probe(void);
+/* Bind this process to one device (one process per GPU; LOCAL_RANK under torch.distributed). */
+int lzgpu_init(int device_index);
+void lzgpu_shutdown(void);
+void lzgpu_free(void* p);
+const char* lzgpu_last_error(void);
+
+/* ---- B1: position table -------------------------------------------------------------------
+ * Replaces build_seed_position_table(seq, start, end, upperCharToBits, seed, step)
+ * (src/pos_table.c:144-196).  Uploads the target bytes t[0..tlen) (seq->v, src/sequences.h:385)
+ * and builds, on the device, the table of all seed words whose window lies in [start,end)
+ * (end==0 means tlen), contains only bytes with char_to_bits[b] >= 0 and ends on a multiple of
+ * step (src/pos_table.c:396-476).  Device layout is CSR (word -> end positions in DESCENDING
+ * order, i.e. the order the reference's last[]/prev[] chain yields them, src/pos_table.c:1341). */
+int lzgpu_table_prepare(const uint8_t* t, uint32_t tlen, uint32_t start, uint32_t end,
+                        const int8_t char_to_bits[256], const lz_seed_desc* seed, uint32_t step);
+/* Copy the table back in the reference's own layout (postable.last[1<<weight],
+ * postable.prev[1+(end-adjStart)/step], src/pos_table.h:126-165) so that host code which reads
+ * the table (capsule writer, --tableonly, masking) keeps working.  Either pointer may be NULL. */
+int lzgpu_table_export(uint32_t* last, uint32_t* prev);
+/* Rebuild the table from the target bytes already resident in HBM (same geometry as the last
+ * lzgpu_table_prepare); used to time B1 without the host->device copy. */
+int lzgpu_table_rebuild(void);
+uint64_t lzgpu_table_num_words(void);
+
+/* Multi-GPU: the table is built once (rank 0) and broadcast over RCCL/xGMI by the caller, which
+ * owns the communicator.  The three device buffers are plain allocations; non-root ranks call
+ * lzgpu_table_adopt() with the root's geometry to allocate them, the caller broadcasts
+ * buf[i] (bytes[i] each), then every rank calls lzgpu_table_commit(). */
+typedef struct lz_table_geom {
+    uint32_t tlen, start, end, step;
+    uint64_t num_words;
+    lz_seed_desc seed;
+    int8_t   char_to_bits[256];
+} lz_table_geom;
+int lzgpu_table_geom(lz_table_geom* out);
+int lzgpu_table_adopt(const lz_table_geom* geom);
+int lzgpu_table_buffers(void* dev_ptr[3], uint64_t bytes[3]);   /* target bytes, wstart, wpos */
+int lzgpu_table_commit(void);
+/* device-to-device copy on the library's stream (lets a caller that received the broadcast in
+ * its own allocation hand it over without knowing which HIP runtime object owns the stream). */
+int lzgpu_device_copy(void* dst_dev, const void* src_dev, uint64_t bytes);
+
+/* ---- B2: seed hit search ------------------------------------------------------------------
+ * Replaces seed_hit_search(seq1, pt, seq2, start, end, selfCompare, charToBits, hitSeed,
+ * searchLimit, reportSearchLimit, bandWidth, processor, processorInfo) for
+ * processor == process_for_simple_hit with gfExtend == gfexXDrop (src/seed_search.c:322-574,
+ * 810-875, 1056-1192, 2528-2959), or process_for_plain_hit when extend==0 (:995-1029).
+ * The fields mirror hitprocinfo (src/seed_search.h:112-156). */
+typedef struct lz_search_args {
+    const uint8_t* query;          /* seq2->v, or NULL to use a resident query slot             */
+    uint32_t       qlen;           /* seq2->len                                                  */
+    int32_t        query_slot;     /* used when query==NULL: slot filled by lzgpu_query_upload   */
+    uint32_t       start, end;     /* search interval in the query; end==0 means qlen            */
+    const int32_t* sub;            /* hp->scoring->sub (maskedScoring): [256][256], row=target   */
+    int32_t        xdrop;          /* hp->xDrop                                                  */
+    int32_t        hsp_threshold;  /* hp->hspThreshold.s ('S' thresholds only)                   */
+    int32_t        entropic;       /* hp->entropicHsp                                            */
+    int32_t        extend;         /* 1: gfexXDrop via simple-hit processor; 0: plain raw hits   */
+} lz_search_args;
+
+typedef struct lz_hsp {            /* exactly what hp->reporter receives (src/seed_search.h:62-81) */
+    uint32_t pos1, pos2;           /* END of the HSP in target / query (exclusive)               */
+    uint32_t length;
+    int32_t  score;
+} lz_hsp;
+
+/* HSPs come back in the reference's discovery order (query position ascending, probe order,
+ * target position descending).  *out is released with lzgpu_free(). */
+int lzgpu_seed_hit_search(const lz_search_args* args, lz_hsp** out, uint64_t* n_out);
+
+/* Keep a query resident in HBM across calls (bench.py: "inputs already resident"). */
+int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen);
+
+/* ---- B3: gapped extension -----------------------------------------------------------------
+ * Replaces reduce_to_points(seq1,seq2,scoring,anchors) + gapped_extend(seq1,rev1,seq2,rev2,
+ * inhibitTrivial,scoring,anchors,tb,allBounds,yDrop,trimToPeak,scoreThresh,...)
+ * (src/gapped_extend.c:463-559,1012-1604) for non-partitioned sequences, allBounds==0,
+ * trimToPeak==1, 'S' thresholds. */
+typedef struct lz_segment {        /* struct segment, src/segment.h:46-60                         */
+    uint32_t pos1, pos2, length;
+    int32_t  s;
+    int32_t  id;
+} lz_segment;
+
+typedef struct lz_gapped_args {
+    const uint8_t* query;          /* seq2->v or NULL + query_slot                                */
+    uint32_t       qlen;
+    int32_t        query_slot;
+    const int32_t* sub;            /* scoring->sub (UNmasked, src/lastz.c:3421)                   */
+    int32_t        gap_open, gap_extend;   /* scoring->gapOpen, scoring->gapExtend               */
+    int32_t        ydrop;
+    int32_t        score_thresh;   /* gappedThreshold.s                                           */
+    uint32_t       traceback_bytes;/* tb->size (0: the reference default, 80 MiB)                 */
+    lz_segment*    anchors;        /* anchors->seg (HSPs; reduced to points and re-sorted in place,
+                                      as the reference does)                                      */
+    uint32_t       n_anchors;
+    int32_t        reduce;         /* 1: run reduce_to_points first                               */
+} lz_gapped_args;
+
+typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */
+    uint32_t beg1, beg2, end1, end2;   /* origin-1, inclusive                                     */
+    int32_t  s;
+    uint32_t script_len;           /* number of editop words                                      */
+    uint32_t script_off;           /* offset of this script in *ops                               */
+} lz_align;
+
+/* Alignments in the reference's output order (increasing start in the target,
+ * src/gapped_extend.c:1475-1566).  ops are the reference's editop words:
+ * (repeat<<2)|op with op 1=ins 2=del 3=sub (src/edit_script.h:48-70). */
+int lzgpu_gapped_extend(const lz_gapped_args* args, lz_align** out, uint64_t* n_out,
+                        uint32_t** ops, uint64_t* n_ops);
+
+/* ---- instrumentation (bench.py, tests) ---------------------------------------------------- */
+typedef struct lz_counters {       /* same events as the reference's collect_stats build          */
+    uint64_t words;                /* "words in seq 2"    src/seed_search.c:514                   */
+    uint64_t raw_hits;             /* "raw seed hits"     src/seed_search.c:865                   */
+    uint64_t extensions;           /* "GF extensions"                                             */
+    uint64_t bp_extended;          /* "bp extended"       src/seed_search.c:2818                  */
+    uint64_t hsps;                 /* "HSPs"                                                      */
+    uint64_t dp_cells;             /* "DP cells visited"  src/gapped_extend.c:3599,3778           */
+    uint64_t gapped_extensions;    /* one-sided DPs run (including speculative re-runs)           */
+    uint64_t anchors_extended;
+} lz_counters;
+void lzgpu_counters_reset(void);
+int  lzgpu_counters_get(lz_counters* out);
+
+/* Per-kernel HIP-event timing on the library's own stream.  enable!=0 brackets every launch
+ * with hipEventRecord; times are accumulated per kernel name. */
+void lzgpu_profile_enable(int enable);
+void lzgpu_profile_reset(void);
+/* n-th kernel (0-based) -> name, launches, total ms; returns 0, or 1 past the end. */
+int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* total_ms);
+
+/* Tuning knobs (tests use small values to exercise the multi-chunk paths). */
+int lzgpu_set_hit_capacity(uint64_t max_hits_per_chunk);
+int lzgpu_set_hsp_capacity(uint64_t max_candidate_hsps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZGPU_H */

@@ -1,0 +1,95 @@
+// lz_ctx.hpp -- per-process device context of liblzgpu (one process per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "lz_common.hpp"
+#include "../../include/lzgpu.h"
+
+struct DevBuf {                     // growable device allocation
+    void*  p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);       // 0 or LZGPU_ERR_OOM; contents are NOT preserved on growth
+    void release();
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct KernelTimer {
+    struct Pending { int id; hipEvent_t a, b; };
+    bool enabled = false;
+    std::vector<std::string> names;
+    std::vector<uint64_t> launches;
+    std::vector<double> ms;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    int  id_of(const char* name);
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void resolve();                 // after a stream sync: fold pending events into totals
+    void reset();
+    hipEvent_t get_event();
+    int cur = -1; hipEvent_t cur_a = nullptr;
+};
+
+struct SeqSlot {                    // a sequence resident in HBM
+    DevBuf raw;                     // LZ_SEQ_PAD + len + LZ_SEQ_PAD bytes
+    DevBuf code;                    // same geometry, code bytes (see lz_common.hpp)
+    u32    len = 0;
+    bool   have_raw = false;
+    uint64_t code_key = 0;          // hash of the (class map, charToBits) the codes were built with
+    std::vector<u8> host;           // host copy (entropy post-pass needs the raw bytes)
+    u8* raw_base()  const { return raw.as<u8>()  + LZ_SEQ_PAD; }
+    u8* code_base() const { return code.as<u8>() + LZ_SEQ_PAD; }
+};
+
+struct LzCtx {
+    bool inited = false;
+    int  device = -1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // ---- target + position table (B1)
+    SeqSlot target;
+    bool have_table = false;
+    lz_table_geom geom;
+    LzSeedDev seed;
+    DevBuf wstart, wpos;            // CSR table
+    u64 num_words = 0;
+
+    // ---- queries
+    std::map<int, SeqSlot> queries; // slot -> resident query; slot -1 = transient
+
+    // ---- seed-search scratch
+    DevBuf cnt, off;                // per query position: raw-hit count (u32) and exclusive scan (u64)
+    DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
+    DevBuf sort_tmp, scan_tmp;
+    DevBuf bstart;                  // [LZ_DIAG_SIZE+1]
+    DevBuf diag_end;                // [LZ_DIAG_SIZE]
+    DevBuf score_tab;               // [32*32] s32
+    DevBuf hsp_out, hsp_count;      // candidates + counter
+    DevBuf dev_counters;            // u64[8]
+    DevBuf tb_keys, tb_vals, tb_keys2, tb_vals2;   // table build scratch
+    u64 hit_capacity = (1ull << 28);
+    u64 hsp_capacity = (1ull << 24);
+
+    lz_counters counters = {};
+    KernelTimer timer;
+};
+
+LzCtx& lz_ctx();
+int lz_fail(int code, const char* fmt, ...);
+#define LZ_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+    return lz_fail(LZGPU_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); } while (0)
+
+// ---- launchers implemented in seed_kernels.hip (all asynchronous on ctx.stream) ----
+int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev);
+int lzk_table_build(LzCtx& c);
+int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u64* valid_words_dev);
+int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
+int lzk_fill_hits(LzCtx& c, const u8* qcode, u32 lo, u32 i0, u32 i1, const u32* cnt, const u64* off, u64 base, u64* keys);
+int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u64 n);
+int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart);
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* bstart, u32* diag_end,
+               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters);

@@ -1,0 +1,175 @@
+// lz_host.cpp -- see lz_host.hpp
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include "lz_host.hpp"
+
+// strict-seed compilation, restating src/seeds.c:321-640 (parse_one_seed; flips in
+// "maintainFlippedBitOrder" order, :603-613) and :1399-1417 (best_shift)
+extern "C" int lzgpu_seed_from_pattern(const char* pattern, int with_trans, lz_seed_desc* out)
+{
+    if (!pattern || !out) return LZGPU_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    const char* s = pattern; const char* e = pattern + strlen(pattern);
+    while (s < e && (*s == '0' || *s == 'X' || *s == 'x')) s++;
+    if (s >= e) return LZGPU_NH_SEED;
+    e--;
+    while (*e == '0' || *e == 'X' || *e == 'x') e--;
+    u64 seed_bits = 0, flip_bits = 0; int length = 0, weight = 0;
+    for (const char* c = s; c <= e; c++) {
+        if (*c == '1') { seed_bits = (seed_bits << 2) + 3; flip_bits = (flip_bits << 2) + 2; length++; weight += 2; }
+        else if (*c == '0' || *c == 'X' || *c == 'x') { seed_bits <<= 2; flip_bits <<= 2; length++; }
+        else return LZGPU_NH_SEED;                   // 'T' (half-weight) positions: CPU path
+    }
+    if (length > 31 || weight > 28 || weight == 0) return LZGPU_NH_SEED;   // src/pos_table.c:1057
+    u32 wbits = (u32)((1ull << weight) - 1), covered = (u32)(seed_bits & wbits);
+    u64 rem = seed_bits - covered;
+    int np = 1;
+    out->shift[0] = 0; out->mask[0] = covered;
+    while (covered != wbits) {
+        u32 uncovered = (~covered) & wbits;
+        int best_cov = -1, best = -1, sh = 0;
+        for (u64 sb = rem; sb != 0; sb >>= 1, sh++) {
+            int cov = __builtin_popcount((u32)(sb & uncovered));
+            if (cov > best_cov) { best_cov = cov; best = sh; }
+        }
+        u32 mask = (u32)(rem >> best) & uncovered;
+        covered += mask; rem -= ((u64)mask) << best;
+        if (np >= LZGPU_MAX_PARTS) return LZGPU_NH_SEED;
+        out->shift[np] = best; out->mask[np] = mask; np++;
+    }
+    out->num_parts = np; out->length = length; out->weight_bits = weight;
+    u32 flips[32]; int nf = 0;
+    while (flip_bits != 0) {
+        u64 right = flip_bits - (flip_bits & (flip_bits - 1));
+        flip_bits -= right;
+        u32 packed = 0;
+        for (int p = 0; p < np; p++) packed |= (u32)(right >> out->shift[p]) & out->mask[p];
+        flips[nf++] = packed;
+    }
+    int npb = 0;
+    out->probe_xor[npb++] = 0;
+    if (with_trans == 1) for (int i = 0; i < nf; i++) out->probe_xor[npb++] = flips[i];
+    else if (with_trans >= 2)
+        for (int i = 0; i < nf; i++) {
+            if (npb >= LZGPU_MAX_PROBES) return LZGPU_NH_SEED;
+            out->probe_xor[npb++] = flips[i];
+            for (int j = i + 1; j < nf; j++) {
+                if (npb >= LZGPU_MAX_PROBES) return LZGPU_NH_SEED;
+                out->probe_xor[npb++] = flips[i] ^ flips[j];
+            }
+        }
+    out->num_probes = npb;
+    return 0;
+}
+
+int lzh_seed_to_dev(const lz_seed_desc* sd, LzSeedDev& d)
+{
+    if (sd->length < 2 || sd->length > 31 || sd->weight_bits < 1 || sd->weight_bits > 28) return LZGPU_NH_SEED;
+    if (sd->num_parts < 1 || sd->num_parts > LZ_MAX_PARTS) return LZGPU_NH_SEED;
+    if (sd->num_probes < 1 || sd->num_probes > LZ_MAX_PROBES) return LZGPU_NH_SEED;
+    memset(&d, 0, sizeof(d));
+    d.length = sd->length; d.weight = sd->weight_bits; d.nparts = sd->num_parts; d.nprobes = sd->num_probes;
+    for (int i = 0; i < sd->num_parts; i++) { d.shift[i] = sd->shift[i]; d.mask[i] = sd->mask[i]; }
+    for (int i = 0; i < sd->num_probes; i++) d.probe_xor[i] = sd->probe_xor[i];
+    return 0;
+}
+
+void lzh_make_cls(const u8* score_class, const int8_t ctb[256], u8 cls[256])
+{
+    for (int b = 0; b < 256; b++) {
+        u8 v = score_class ? (u8)(score_class[b] & 31) : 0;
+        if (ctb[b] < 0) v |= LZ_CODE_INVALID; else v |= (u8)((ctb[b] & 3) << 5);
+        cls[b] = v;
+    }
+}
+
+// Compress the 256x256 matrix to <=32 row classes x <=32 column classes (bytes whose rows /
+// columns are identical are interchangeable for scoring).  Exact for any matrix that fits.
+int lzh_score_classes(const s32* sub, u8 rowc[256], u8 colc[256], s32 tab[LZ_NCLASS * LZ_NCLASS])
+{
+    int rep_r[LZ_NCLASS], rep_c[LZ_NCLASS], nr = 0, nc = 0;
+    for (int r = 0; r < 256; r++) {
+        int k;
+        for (k = 0; k < nr; k++) if (memcmp(sub + 256 * r, sub + 256 * rep_r[k], 256 * sizeof(s32)) == 0) break;
+        if (k == nr) { if (nr == LZ_NCLASS) return LZGPU_NH_SCORE_CLASSES; rep_r[nr++] = r; }
+        rowc[r] = (u8)k;
+    }
+    std::vector<s32> tr(65536);
+    for (int r = 0; r < 256; r++) for (int cc = 0; cc < 256; cc++) tr[256 * cc + r] = sub[256 * r + cc];
+    for (int cc = 0; cc < 256; cc++) {
+        int k;
+        for (k = 0; k < nc; k++) if (memcmp(&tr[256 * cc], &tr[256 * rep_c[k]], 256 * sizeof(s32)) == 0) break;
+        if (k == nc) { if (nc == LZ_NCLASS) return LZGPU_NH_SCORE_CLASSES; rep_c[nc++] = cc; }
+        colc[cc] = (u8)k;
+    }
+    for (int i = 0; i < LZ_NCLASS * LZ_NCLASS; i++) tab[i] = 0;
+    for (int a = 0; a < nr; a++) for (int b = 0; b < nc; b++) tab[a * LZ_NCLASS + b] = sub[256 * rep_r[a] + rep_c[b]];
+    return 0;
+}
+
+// src/dna_utilities.c:2888-2936 (compute_entropy with lowerOk == false); same operation order
+double lzh_hsp_entropy(const u8* s, const u8* t, int len)
+{
+    int cA = 0, cC = 0, cG = 0, cT = 0;
+    for (int ix = 0; ix < len; ix++) {
+        if (s[ix] != t[ix]) continue;
+        switch (s[ix]) { case 'A': cA++; break; case 'C': cC++; break; case 'G': cG++; break; case 'T': cT++; break; default: break; }
+    }
+    if (cA + cC + cG + cT < 20) return 1.0;
+    double pA = ((double)cA) / ((double)len), pC = ((double)cC) / ((double)len);
+    double pG = ((double)cG) / ((double)len), pT = ((double)cT) / ((double)len);
+    double qA = (cA != 0) ? log(pA) : 0.0, qC = (cC != 0) ? log(pC) : 0.0;
+    double qG = (cG != 0) ? log(pG) : 0.0, qT = (cT != 0) ? log(pT) : 0.0;
+    return -(pA * qA + pC * qC + pG * qG + pT * qT) / log(4.0);
+}
+
+static bool host_window_word(const u8* seq, u32 pos, const LzSeedDev& sd, const int8_t* ctb, u32& packed)
+{
+    u64 w = 0;
+    for (int k = 0; k < sd.length; k++) {
+        int b = ctb[seq[pos - sd.length + k]];
+        if (b < 0) return false;
+        w = (w << 2) | (u64)b;
+    }
+    packed = lz_apply_seed(sd, w);
+    return true;
+}
+
+struct RecKey { u32 pos2, probe, pos1, idx; };
+
+int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
+                    const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
+                    std::vector<lz_hsp>& out)
+{
+    out.clear();
+    std::vector<RecKey> order(n_rec);
+    for (u32 i = 0; i < n_rec; i++) {
+        u32 pt = 0, pq = 0, probe = 0;
+        if (!host_window_word(thost, recs[i].seed_pos1, sd, ctb, pt) ||
+            !host_window_word(qhost, recs[i].seed_pos2, sd, ctb, pq)) return LZGPU_ERR_STATE;
+        u32 x = pt ^ pq;
+        for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break;
+        if (probe == (u32)sd.nprobes) return LZGPU_ERR_STATE;
+        order[i] = { recs[i].seed_pos2, probe, recs[i].seed_pos1, i };
+    }
+    std::sort(order.begin(), order.end(), [](const RecKey& x, const RecKey& y) {
+        if (x.pos2 != y.pos2) return x.pos2 < y.pos2;
+        if (x.probe != y.probe) return x.probe < y.probe;
+        return x.pos1 > y.pos1;
+    });
+    const s32 zero_thresh = K > 0 ? K : 0;                      // src/lastz.c:2937-2939
+    for (u32 k = 0; k < n_rec; k++) {
+        const LzHspRec& r = recs[order[k].idx];
+        s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+        u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
+        s32 sim = r.score;
+        if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
+            double q = lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
+            sim = (s32)(sim * q);                               // "similarity *= q" on an s32 score
+        }
+        if (sim < K) continue;
+        out.push_back({ pos1, pos2, length, sim });
+    }
+    return 0;
+}

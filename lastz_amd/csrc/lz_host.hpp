@@ -1,0 +1,53 @@
+// lz_host.hpp -- the pure-host pieces of the seed stage (no HIP calls): seed compilation, score
+// class compression, chunk planning and the per-HSP finish.  Kept free of device code so that
+// tests/emul can link them and check them on a machine without a GPU.
+#pragma once
+#include <vector>
+#include "lz_common.hpp"
+#include "../../include/lzgpu.h"
+
+int  lzh_seed_to_dev(const lz_seed_desc* sd, LzSeedDev& d);
+void lzh_make_cls(const u8* score_class /*[256] or NULL*/, const int8_t ctb[256], u8 cls[256]);
+int  lzh_score_classes(const s32* sub, u8 rowc[256], u8 colc[256], s32 tab[LZ_NCLASS * LZ_NCLASS]);
+double lzh_hsp_entropy(const u8* s, const u8* t, int len);
+
+struct LzChunk { u32 i0, i1; u64 base, nh; };
+// Split query positions [0,n) into chunks of at most cap raw hits.  off_at(i) must return the
+// exclusive prefix sum of the per-position hit counts at i (i in [0,n]); samples are taken every
+// S positions first and refined only where one S-block alone exceeds cap.
+template <class OffAt>
+int lzh_plan_chunks(u32 n, u64 cap, u32 S, OffAt&& off_at, std::vector<LzChunk>& chunks)
+{
+    chunks.clear();
+    const u32 ns = (n + S - 1) / S;
+    auto samp = [&](u32 s) -> u64 { u64 i = (u64)s * S; return off_at(i < n ? (u32)i : n); };
+    u32 s0 = 0;
+    while (s0 < ns) {
+        u32 s1 = s0;
+        while (s1 < ns && samp(s1 + 1) - samp(s0) <= cap) s1++;
+        if (s1 > s0) {
+            u32 i0 = s0 * S, i1 = ((u64)s1 * S < n) ? s1 * S : n;
+            if (samp(s1) > samp(s0)) chunks.push_back({ i0, i1, samp(s0), samp(s1) - samp(s0) });
+            s0 = s1;
+            continue;
+        }
+        u32 b0 = s0 * S, b1 = ((u64)(s0 + 1) * S < n) ? (s0 + 1) * S : n;
+        u32 p0 = b0;
+        while (p0 < b1) {
+            u32 p1 = p0;
+            while (p1 < b1 && off_at(p1 + 1) - off_at(p0) <= cap) p1++;
+            if (p1 == p0) return LZGPU_NH_HITS_OVERFLOW;
+            if (off_at(p1) > off_at(p0)) chunks.push_back({ p0, p1, off_at(p0), off_at(p1) - off_at(p0) });
+            p0 = p1;
+        }
+        s0++;
+    }
+    return 0;
+}
+
+// Candidate HSPs (any order) -> what the reference's reporter sees, in discovery order:
+// (query position of the seed hit ascending, probe index, target position descending), entropy
+// adjustment (src/seed_search.c:2851-2874) and the score threshold (:2907-2933).
+int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
+                    const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
+                    std::vector<lz_hsp>& out);

@@ -1,0 +1,460 @@
+// lzgpu_api.hip -- C ABI (include/lzgpu.h), device context and host-side orchestration of the
+// seed stage.  The host work here is what the reference does around its hot loops and is not
+// data-parallel: seed compilation (src/seeds.c), score-class compression of the 256x256 matrix,
+// chunk planning, and the per-HSP finish (discovery ordering + the floating-point entropy
+// adjustment of src/seed_search.c:2851-2874, src/dna_utilities.c:2888-2936).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include "lz_ctx.hpp"
+#include "lz_host.hpp"
+
+// ------------------------------------------------------------------------------ context
+
+static LzCtx g_ctx;
+LzCtx& lz_ctx() { return g_ctx; }
+
+int lz_fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_ctx.last_error = buf;
+    return code;
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap && p) return 0;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { p = nullptr; return lz_fail(LZGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+    cap = want;
+    return 0;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+int KernelTimer::id_of(const char* name)
+{
+    for (size_t i = 0; i < names.size(); i++) if (names[i] == name) return (int)i;
+    names.push_back(name); launches.push_back(0); ms.push_back(0.0);
+    return (int)names.size() - 1;
+}
+hipEvent_t KernelTimer::get_event()
+{
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void KernelTimer::begin(const char* name, hipStream_t s)
+{
+    if (!enabled) return;
+    cur = id_of(name); cur_a = get_event();
+    (void)hipEventRecord(cur_a, s);
+}
+void KernelTimer::end(hipStream_t s)
+{
+    if (!enabled || cur < 0) return;
+    hipEvent_t b = get_event();
+    (void)hipEventRecord(b, s);
+    pending.push_back({cur, cur_a, b});
+    cur = -1; cur_a = nullptr;
+}
+void KernelTimer::resolve()
+{
+    for (auto& p : pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; launches[p.id]++; }
+        pool.push_back(p.a); pool.push_back(p.b);
+    }
+    pending.clear();
+}
+void KernelTimer::reset() { resolve(); for (auto& x : ms) x = 0; for (auto& x : launches) x = 0; }
+
+static int require_init()
+{
+    if (!g_ctx.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    return 0;
+}
+
+extern "C" const char* lzgpu_last_error(void) { return g_ctx.last_error.c_str(); }
+
+extern "C" int lzgpu_probe(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return lz_fail(LZGPU_ERR_NO_DEVICE, "no HIP device visible");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return lz_fail(LZGPU_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return lz_fail(LZGPU_ERR_NO_DEVICE, "device 0 is %s, this library is built for gfx950 only", prop.gcnArchName);
+    return 0;
+}
+
+extern "C" int lzgpu_init(int device_index)
+{
+    if (g_ctx.inited && (device_index < 0 || device_index == g_ctx.device)) return 0;
+    if (g_ctx.inited) return lz_fail(LZGPU_ERR_STATE, "already bound to device %d", g_ctx.device);
+    int rc = lzgpu_probe();
+    if (rc) return rc;
+    if (device_index < 0) {
+        const char* lr = getenv("LOCAL_RANK");
+        device_index = lr ? atoi(lr) : 0;
+        int n = 0; (void)hipGetDeviceCount(&n);
+        if (n > 0) device_index %= n;
+    }
+    LZ_HIP(hipSetDevice(device_index));
+    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    g_ctx.device = device_index;
+    g_ctx.inited = true;
+    return 0;
+}
+
+extern "C" void lzgpu_shutdown(void)
+{
+    LzCtx& c = g_ctx;
+    if (!c.inited) return;
+    (void)hipStreamSynchronize(c.stream);
+    c.timer.resolve();
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.keys_a, &c.keys_b,
+                       &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
+                       &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
+    for (DevBuf* b : bufs) b->release();
+    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); }
+    c.queries.clear();
+    (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr; c.inited = false; c.have_table = false; c.device = -1;
+}
+
+extern "C" void lzgpu_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------ sequences
+
+static int slot_upload(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len, bool keep_host)
+{
+    int rc;
+    size_t total = (size_t)len + 2 * LZ_SEQ_PAD + 16;
+    if ((rc = s.raw.ensure(total))) return rc;
+    if ((rc = s.code.ensure(total))) return rc;
+    LZ_HIP(hipMemsetAsync(s.raw.p, 0, total, c.stream));
+    LZ_HIP(hipMemsetAsync(s.code.p, LZ_CODE_INVALID, total, c.stream));
+    if (len) LZ_HIP(hipMemcpyAsync(s.raw_base(), bytes, len, hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    s.len = len; s.have_raw = true; s.code_key = 0;
+    if (keep_host) s.host.assign(bytes, bytes + len); else s.host.clear();
+    return 0;
+}
+
+static uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const u8* b = (const u8*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
+
+// encode slot with table cls (class | bits<<5 | invalid<<7), unless already encoded with it
+static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
+{
+    uint64_t key = fnv1a(cls, 256);
+    if (s.code_key == key) return 0;
+    int rc;
+    if ((rc = cls_dev.ensure(256))) return rc;
+    LZ_HIP(hipMemcpyAsync(cls_dev.p, cls, 256, hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));          // cls is caller stack memory
+    if ((rc = lzk_encode(c, s.raw_base(), s.code_base(), s.len, cls_dev.as<u8>()))) return rc;
+    s.code_key = key;
+    return 0;
+}
+
+static DevBuf g_cls_t, g_cls_q;
+
+extern "C" int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen)
+{
+    int rc = require_init(); if (rc) return rc;
+    if (slot < 0 || !q) return lz_fail(LZGPU_ERR_ARG, "bad query slot");
+    if (qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+    return slot_upload(g_ctx, g_ctx.queries[slot], q, qlen, true);
+}
+
+// ------------------------------------------------------------------------------ B1
+
+extern "C" int lzgpu_table_prepare(const uint8_t* t, uint32_t tlen, uint32_t start, uint32_t end,
+                                   const int8_t char_to_bits[256], const lz_seed_desc* seed, uint32_t step)
+{
+    int rc = require_init(); if (rc) return rc;
+    LzCtx& c = g_ctx;
+    if (!t || !seed || !char_to_bits) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    if (step < 1) return lz_fail(LZGPU_ERR_ARG, "in build_seed_position_table(), step can't be %u", step);
+    if (end == 0) end = tlen;
+    if (end <= start) return lz_fail(LZGPU_ERR_ARG, "interval is void (%u..%u)", start, end);
+    if (end > tlen)   return lz_fail(LZGPU_ERR_ARG, "interval end is bad (%u>%u)", end, tlen);
+    if (tlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+    if ((rc = lzh_seed_to_dev(seed, c.seed))) return rc;
+
+    c.have_table = false;
+    memset(&c.geom, 0, sizeof(c.geom));
+    c.geom.tlen = tlen; c.geom.start = start; c.geom.end = end; c.geom.step = step; c.geom.seed = *seed;
+    memcpy(c.geom.char_to_bits, char_to_bits, 256);
+    if ((rc = slot_upload(c, c.target, t, tlen, true))) return rc;
+    u8 cls[256]; lzh_make_cls(nullptr, char_to_bits, cls);
+    if ((rc = slot_encode(c, c.target, cls, g_cls_t))) return rc;
+    if ((rc = lzk_table_build(c))) return rc;
+    c.geom.num_words = c.num_words;
+    c.have_table = true;
+    return 0;
+}
+
+extern "C" int lzgpu_table_rebuild(void)
+{
+    LzCtx& c = g_ctx;
+    if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "no position table");
+    int rc = lzk_table_build(c);
+    if (!rc) c.geom.num_words = c.num_words;
+    return rc;
+}
+
+extern "C" uint64_t lzgpu_table_num_words(void) { return g_ctx.have_table ? g_ctx.num_words : 0; }
+
+extern "C" int lzgpu_table_export(uint32_t* last, uint32_t* prev)
+{
+    LzCtx& c = g_ctx;
+    if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "no position table");
+    u32 nwords = 1u << c.seed.weight;
+    u32 adj = c.geom.start - (c.geom.start % c.geom.step);
+    u32 prev_entries = 1 + (c.geom.end - adj) / c.geom.step;       // src/pos_table.c:1065
+    DevBuf dl, dp; int rc;
+    if (last && (rc = dl.ensure((size_t)nwords * 4))) return rc;
+    if (prev && (rc = dp.ensure((size_t)prev_entries * 4))) { dl.release(); return rc; }
+    rc = lzk_table_export(c, last ? dl.as<u32>() : nullptr, prev ? dp.as<u32>() : nullptr, prev_entries);
+    if (!rc) {
+        if (last) (void)hipMemcpyAsync(last, dl.p, (size_t)nwords * 4, hipMemcpyDeviceToHost, c.stream);
+        if (prev) (void)hipMemcpyAsync(prev, dp.p, (size_t)prev_entries * 4, hipMemcpyDeviceToHost, c.stream);
+        if (hipStreamSynchronize(c.stream) != hipSuccess) rc = lz_fail(LZGPU_ERR_HIP, "table export copy failed");
+    }
+    dl.release(); dp.release();
+    return rc;
+}
+
+extern "C" int lzgpu_table_geom(lz_table_geom* out)
+{
+    if (!g_ctx.have_table || !out) return lz_fail(LZGPU_ERR_STATE, "no position table");
+    *out = g_ctx.geom; return 0;
+}
+
+extern "C" int lzgpu_table_adopt(const lz_table_geom* g)
+{
+    int rc = require_init(); if (rc) return rc;
+    LzCtx& c = g_ctx;
+    if (!g) return LZGPU_ERR_ARG;
+    if ((rc = lzh_seed_to_dev(&g->seed, c.seed))) return rc;
+    c.have_table = false; c.geom = *g; c.num_words = g->num_words;
+    size_t total = (size_t)g->tlen + 2 * LZ_SEQ_PAD + 16;
+    if ((rc = c.target.raw.ensure(total))) return rc;
+    if ((rc = c.target.code.ensure(total))) return rc;
+    LZ_HIP(hipMemsetAsync(c.target.raw.p, 0, total, c.stream));
+    LZ_HIP(hipMemsetAsync(c.target.code.p, LZ_CODE_INVALID, total, c.stream));
+    c.target.len = g->tlen; c.target.have_raw = true; c.target.code_key = 0; c.target.host.clear();
+    if ((rc = c.wstart.ensure(((size_t)(1u << c.seed.weight) + 1) * 4))) return rc;
+    if ((rc = c.wpos.ensure((size_t)(g->num_words ? g->num_words : 1) * 4))) return rc;
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+extern "C" int lzgpu_table_buffers(void* dev_ptr[3], uint64_t bytes[3])
+{
+    LzCtx& c = g_ctx;
+    if (!c.target.have_raw || !c.wstart.p) return lz_fail(LZGPU_ERR_STATE, "no table buffers");
+    dev_ptr[0] = c.target.raw_base(); bytes[0] = c.geom.tlen;
+    dev_ptr[1] = c.wstart.p;          bytes[1] = ((uint64_t)(1u << c.seed.weight) + 1) * 4;
+    dev_ptr[2] = c.wpos.p;            bytes[2] = (uint64_t)c.num_words * 4;
+    return 0;
+}
+
+extern "C" int lzgpu_table_commit(void)
+{
+    LzCtx& c = g_ctx;
+    if (!c.target.have_raw || !c.wstart.p) return lz_fail(LZGPU_ERR_STATE, "no table buffers");
+    // the entropy finish needs the target bytes on the host as well
+    c.target.host.resize(c.geom.tlen);
+    if (c.geom.tlen) LZ_HIP(hipMemcpy(c.target.host.data(), c.target.raw_base(), c.geom.tlen, hipMemcpyDeviceToHost));
+    c.target.code_key = 0;
+    c.have_table = true;
+    return 0;
+}
+
+extern "C" int lzgpu_device_copy(void* dst, const void* src, uint64_t bytes)
+{
+    int rc = require_init(); if (rc) return rc;
+    if (!bytes) return 0;
+    LZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
+    LZ_HIP(hipStreamSynchronize(g_ctx.stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ B2
+
+extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint64_t* n_out)
+{
+    int rc = require_init(); if (rc) return rc;
+    LzCtx& c = g_ctx;
+    if (!a || !out || !n_out || !a->sub) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    *out = nullptr; *n_out = 0;
+    if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_prepare has not been called");
+
+    // ---- query
+    SeqSlot* qs;
+    if (a->query) {
+        if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+        qs = &c.queries[-1];
+        if ((rc = slot_upload(c, *qs, a->query, a->qlen, false))) return rc;
+    } else {
+        auto it = c.queries.find(a->query_slot);
+        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
+        qs = &it->second;
+    }
+    const u8* qhost = a->query ? a->query : qs->host.data();
+    const u32 qlen = qs->len;
+    u32 lo = a->start, hi = a->end ? a->end : qlen;
+    if (hi <= lo) return lz_fail(LZGPU_ERR_ARG, "in seed_hit_search(), interval is void (%u-%u)", lo, hi);
+    if (hi > qlen) return lz_fail(LZGPU_ERR_ARG, "in seed_hit_search(), interval end is bad (%u>%u)", hi, qlen);
+
+    // ---- scoring classes, codes
+    u8 rowc[256], colc[256], cls[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
+    if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
+    if ((rc = c.score_tab.ensure(sizeof(tab)))) return rc;
+    LZ_HIP(hipMemcpyAsync(c.score_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    lzh_make_cls(rowc, c.geom.char_to_bits, cls);
+    if ((rc = slot_encode(c, c.target, cls, g_cls_t))) return rc;
+    lzh_make_cls(colc, c.geom.char_to_bits, cls);
+    if ((rc = slot_encode(c, *qs, cls, g_cls_q))) return rc;
+
+    const u32 L = (u32)c.seed.length;
+    if (qlen < L) return 0;                                     // src/seed_search.c:486-487
+
+    // ---- state
+    const u32 n = hi - lo;
+    if ((rc = c.cnt.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.off.ensure((size_t)n * 8))) return rc;
+    if ((rc = c.bstart.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
+    if ((rc = c.diag_end.ensure((size_t)LZ_DIAG_SIZE * 4))) return rc;
+    if ((rc = c.dev_counters.ensure(8 * 8))) return rc;
+    if ((rc = c.hsp_count.ensure(4))) return rc;
+    LZ_HIP(hipMemsetAsync(c.diag_end.p, 0, (size_t)LZ_DIAG_SIZE * 4, c.stream));      // empty_diag_hash
+    LZ_HIP(hipMemsetAsync(c.dev_counters.p, 0, 64, c.stream));
+    LZ_HIP(hipMemsetAsync(c.hsp_count.p, 0, 4, c.stream));
+    u64* d_counters = c.dev_counters.as<u64>();                 // [0]=extensions [1]=bp [2]=words
+
+    // ---- 1. count + scan
+    if ((rc = lzk_count_hits(c, qs->code_base(), lo, hi, c.cnt.as<u32>(), d_counters + 2))) return rc;
+    if ((rc = lzk_scan_counts(c, c.cnt.as<u32>(), c.off.as<u64>(), n))) return rc;
+
+    u64 last_off = 0; u32 last_cnt = 0;
+    LZ_HIP(hipMemcpyAsync(&last_off, c.off.as<u64>() + (n - 1), 8, hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipMemcpyAsync(&last_cnt, c.cnt.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    c.timer.resolve();
+    const u64 total_hits = last_off + last_cnt;
+
+    // ---- 2. chunk plan: [i0,i1) in query positions with at most hit_capacity hits each.
+    // Prefix sums are sampled every S positions (one strided copy); finer values are fetched
+    // only if a single S-block exceeds the capacity.
+    const u32 S = 4096;
+    const u32 ns = (n + S - 1) / S;
+    std::vector<u64> samp(ns);
+    LZ_HIP(hipMemcpy2D(samp.data(), 8, c.off.p, (size_t)S * 8, 8, ns, hipMemcpyDeviceToHost));
+    std::vector<LzChunk> chunks;
+    hipError_t fetch_err = hipSuccess;
+    auto off_at = [&](u32 i) -> u64 {
+        if (i >= n) return total_hits;
+        if (i % S == 0) return samp[i / S];
+        u64 v = 0;
+        hipError_t e = hipMemcpy(&v, c.off.as<u64>() + i, 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) fetch_err = e;
+        return v;
+    };
+    if ((rc = lzh_plan_chunks(n, c.hit_capacity, S, off_at, chunks))) return rc;
+    if (fetch_err != hipSuccess) return lz_fail(LZGPU_ERR_HIP, "prefix fetch failed: %s", hipGetErrorString(fetch_err));
+
+    u64 max_chunk = 0;
+    for (auto& ch : chunks) if (ch.nh > max_chunk) max_chunk = ch.nh;
+    if (max_chunk) {
+        if ((rc = c.keys_a.ensure((size_t)max_chunk * 8))) return rc;
+        if (a->extend && (rc = c.keys_b.ensure((size_t)max_chunk * 8))) return rc;
+    }
+    const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
+    if (a->extend && (rc = c.hsp_out.ensure((size_t)out_cap * sizeof(LzHspRec)))) return rc;
+
+    LzExtendParams P;
+    P.tcode = c.target.code_base(); P.tlen = c.geom.tlen;
+    P.qcode = qs->code_base();      P.qlen = qlen;
+    P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
+
+    std::vector<lz_hsp> plain;
+    // ---- 3. per chunk: fill -> (stable bucket sort -> bounds -> bucket-serial extension)
+    for (auto& ch : chunks) {
+        if ((rc = lzk_fill_hits(c, qs->code_base(), lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
+        if (!a->extend) {                                       // process_for_plain_hit: report every hit
+            std::vector<u64> hk(ch.nh);
+            LZ_HIP(hipMemcpyAsync(hk.data(), c.keys_a.p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));
+            LZ_HIP(hipStreamSynchronize(c.stream));
+            for (u64 k : hk) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); }
+            continue;
+        }
+        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), c.keys_b.as<u64>(), ch.nh))) return rc;
+        if ((rc = lzk_bucket_bounds(c, c.keys_b.as<u64>(), ch.nh, c.bstart.as<u32>()))) return rc;
+        if ((rc = lzk_extend(c, P, c.keys_b.as<u64>(), c.bstart.as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters))) return rc;
+    }
+
+    u64 hc[3] = { 0, 0, 0 }; u32 n_rec = 0;
+    LZ_HIP(hipMemcpyAsync(hc, d_counters, 24, hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipMemcpyAsync(&n_rec, c.hsp_count.p, 4, hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    c.timer.resolve();
+    c.counters.words += hc[2]; c.counters.raw_hits += total_hits;
+    c.counters.extensions += hc[0]; c.counters.bp_extended += hc[1];
+
+    if (!a->extend) {
+        lz_hsp* res = (lz_hsp*)malloc((plain.size() ? plain.size() : 1) * sizeof(lz_hsp));
+        if (!res) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
+        if (!plain.empty()) memcpy(res, plain.data(), plain.size() * sizeof(lz_hsp));
+        *out = res; *n_out = plain.size();
+        return 0;
+    }
+    if (n_rec > out_cap) return LZGPU_NH_HSP_OVERFLOW;
+
+    // ---- 4. host finish: discovery order, entropy, threshold
+    std::vector<LzHspRec> recs(n_rec);
+    if (n_rec) LZ_HIP(hipMemcpy(recs.data(), c.hsp_out.p, (size_t)n_rec * sizeof(LzHspRec), hipMemcpyDeviceToHost));
+    std::vector<lz_hsp> fin;
+    if ((rc = lzh_finish_hsps(recs.data(), n_rec, c.target.host.data(), qhost, c.seed, c.geom.char_to_bits,
+                              a->hsp_threshold, a->entropic, fin)))
+        return lz_fail(rc, "internal: candidate HSP is not on a seed hit");
+    lz_hsp* res = (lz_hsp*)malloc((fin.size() ? fin.size() : 1) * sizeof(lz_hsp));
+    if (!res) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
+    if (!fin.empty()) memcpy(res, fin.data(), fin.size() * sizeof(lz_hsp));
+    c.counters.hsps += fin.size();
+    *out = res; *n_out = fin.size();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ instrumentation
+
+extern "C" void lzgpu_counters_reset(void) { memset(&g_ctx.counters, 0, sizeof(g_ctx.counters)); }
+extern "C" int  lzgpu_counters_get(lz_counters* out) { if (!out) return LZGPU_ERR_ARG; *out = g_ctx.counters; return 0; }
+extern "C" void lzgpu_profile_enable(int enable) { g_ctx.timer.enabled = enable != 0; }
+extern "C" void lzgpu_profile_reset(void) { g_ctx.timer.reset(); }
+extern "C" int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* total_ms)
+{
+    KernelTimer& t = g_ctx.timer;
+    if (n < 0 || n >= (int)t.names.size()) return 1;
+    if (name) *name = t.names[n].c_str();
+    if (launches) *launches = t.launches[n];
+    if (total_ms) *total_ms = t.ms[n];
+    return 0;
+}
+extern "C" int lzgpu_set_hit_capacity(uint64_t n) { if (n < 1024) return LZGPU_ERR_ARG; g_ctx.hit_capacity = n; return 0; }
+extern "C" int lzgpu_set_hsp_capacity(uint64_t n) { if (n < 16) return LZGPU_ERR_ARG; g_ctx.hsp_capacity = n; return 0; }

@@ -1,0 +1,298 @@
+// seed_kernels.hip -- gfx950 kernels of the seed stage: position-table build (B1), raw-hit
+// enumeration, bucket ordering and the bucket-serial X-drop extender (B2).
+//
+// Decomposition: the only cross-hit state of the reference's HSP search is
+// diagEnd[hashedDiag] (src/seed_search.c:1081-1126, 2612-2616, 2785-2789), so the exact
+// parallel form is 65,536 independent, order-preserving streams.  Hits are enumerated in the
+// reference's order (count -> scan -> fill gives every hit its discovery index), stably
+// partitioned by the 16 hash bits (LSD radix sort restricted to key bits 32..47), and each
+// bucket is then walked by one lane with diagEnd[h] in a register.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include "lz_ctx.hpp"
+
+#define LZ_TPB 256
+
+// ------------------------------------------------------------------------------------------
+// byte -> code translation (one pass per sequence; the table folds charToBits and the score
+// class of the byte, see lz_common.hpp)
+__global__ void __launch_bounds__(LZ_TPB)
+k_encode(const u8* __restrict__ raw, u8* __restrict__ code, u32 len, const u8* __restrict__ cls)
+{
+    __shared__ u8 tab[256];
+    tab[threadIdx.x] = cls[threadIdx.x];
+    __syncthreads();
+    const u32 nvec = (len + 15u) >> 4;                 // buffers are padded: whole 16-byte groups are safe
+    for (u32 v = blockIdx.x * LZ_TPB + threadIdx.x; v < nvec; v += gridDim.x * LZ_TPB) {
+        uint4 x = reinterpret_cast<const uint4*>(raw)[v];
+        u32 w[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 a = w[k];
+            w[k] = (u32)tab[a & 255u] | ((u32)tab[(a >> 8) & 255u] << 8) |
+                   ((u32)tab[(a >> 16) & 255u] << 16) | ((u32)tab[a >> 24] << 24);
+        }
+        reinterpret_cast<uint4*>(code)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev)
+{
+    if (len == 0) return 0;
+    u32 nvec = (len + 15u) >> 4;
+    u32 blocks = (nvec + LZ_TPB - 1) / LZ_TPB; if (blocks > 4096) blocks = 4096;
+    c.timer.begin("k_encode", c.stream);
+    hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(LZ_TPB), 0, c.stream, raw, code, len, cls256_dev);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// B1: position table.  One (word, end position) pair per target position, positions emitted in
+// DESCENDING order so that the stable radix sort by word leaves every word's list in the order
+// the reference's chain walk yields it (most recent first, src/pos_table.c:1341-1344).
+__global__ void __launch_bounds__(LZ_TPB)
+k_table_words(const u8* __restrict__ tcode, u32 start, u32 end, u32 step, LzSeedDev sd,
+              u32* __restrict__ keys, u32* __restrict__ vals, u32 n)
+{
+    u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (j >= n) return;
+    u32 p = end - j;                                    // window is [p-L, p)
+    u32 key = 1u << sd.weight;                          // "no word": sorts after every real word
+    if (p >= start + (u32)sd.length && (p % step) == 0) {
+        u32 packed;
+        if (lz_window_word(tcode, p, sd, packed)) key = packed;
+    }
+    keys[j] = key; vals[j] = p;
+}
+
+// wstart[w] = index of the first sorted entry with key >= w, for w in [0, nwords]
+__global__ void __launch_bounds__(LZ_TPB)
+k_key_bounds_u32(const u32* __restrict__ keys, u32 n, u32 nwords, u32* __restrict__ wstart)
+{
+    u32 i = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (i > n) return;
+    s64 kp = (i == 0) ? -1 : (s64)keys[i - 1];
+    s64 k  = (i == n) ? (s64)nwords : (s64)keys[i];
+    if (k > (s64)nwords) k = nwords;
+    if (kp > (s64)nwords) kp = nwords;
+    for (s64 w = kp + 1; w <= k; w++) wstart[w] = i;
+}
+
+int lzk_table_build(LzCtx& c)
+{
+    const lz_table_geom& g = c.geom;
+    const u32 n = g.end - g.start;
+    const u32 nwords = 1u << c.seed.weight;
+    int rc;
+    if ((rc = c.tb_keys.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.tb_vals.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.tb_keys2.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.tb_vals2.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.wstart.ensure(((size_t)nwords + 1) * 4))) return rc;
+
+    c.timer.begin("k_table_words", c.stream);
+    hipLaunchKernelGGL(k_table_words, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       c.target.code_base(), g.start, g.end, g.step, c.seed,
+                       c.tb_keys.as<u32>(), c.tb_vals.as<u32>(), n);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+
+    size_t tmp = 0;
+    LZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, c.tb_keys.as<u32>(), c.tb_keys2.as<u32>(),
+                                     c.tb_vals.as<u32>(), c.tb_vals2.as<u32>(), (size_t)n, 0u,
+                                     (unsigned)c.seed.weight + 1u, c.stream));
+    if ((rc = c.sort_tmp.ensure(tmp))) return rc;
+    c.timer.begin("rocprim_sort_table", c.stream);
+    LZ_HIP(rocprim::radix_sort_pairs(c.sort_tmp.p, tmp, c.tb_keys.as<u32>(), c.tb_keys2.as<u32>(),
+                                     c.tb_vals.as<u32>(), c.tb_vals2.as<u32>(), (size_t)n, 0u,
+                                     (unsigned)c.seed.weight + 1u, c.stream));
+    c.timer.end(c.stream);
+
+    c.timer.begin("k_key_bounds_u32", c.stream);
+    hipLaunchKernelGGL(k_key_bounds_u32, dim3((n + 1 + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       c.tb_keys2.as<u32>(), n, nwords, c.wstart.as<u32>());
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+
+    u32 nw = 0;
+    LZ_HIP(hipMemcpyAsync(&nw, c.wstart.as<u32>() + nwords, 4, hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    c.timer.resolve();
+    c.num_words = nw;
+    if ((rc = c.wpos.ensure((size_t)(nw ? nw : 1) * 4))) return rc;
+    LZ_HIP(hipMemcpyAsync(c.wpos.p, c.tb_vals2.p, (size_t)nw * 4, hipMemcpyDeviceToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    c.tb_keys.release(); c.tb_vals.release(); c.tb_keys2.release(); c.tb_vals2.release();
+    return 0;
+}
+
+// CSR -> the reference's last[]/prev[] (src/pos_table.h:126-165): one thread per word
+__global__ void __launch_bounds__(LZ_TPB)
+k_table_export(const u32* __restrict__ wstart, const u32* __restrict__ wpos, u32 nwords,
+               u32 adj_start, u32 step, u32* __restrict__ last, u32* __restrict__ prev)
+{
+    u32 w = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (w >= nwords) return;
+    u32 a = wstart[w], b = wstart[w + 1];
+    if (a == b) return;
+    if (last) last[w] = (wpos[a] - adj_start) / step;
+    if (prev)
+        for (u32 j = a; j < b; j++)
+            prev[(wpos[j] - adj_start) / step] = (j + 1 < b) ? (wpos[j + 1] - adj_start) / step : 0xFFFFFFFFu;
+}
+
+int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries)
+{
+    const u32 nwords = 1u << c.seed.weight;
+    if (last_dev) LZ_HIP(hipMemsetAsync(last_dev, 0, (size_t)nwords * 4, c.stream));
+    if (prev_dev) LZ_HIP(hipMemsetAsync(prev_dev, 0, (size_t)prev_entries * 4, c.stream));
+    u32 adj = c.geom.start - (c.geom.start % c.geom.step);
+    hipLaunchKernelGGL(k_table_export, dim3((nwords + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       c.wstart.as<u32>(), c.wpos.as<u32>(), nwords, adj, c.geom.step, last_dev, prev_dev);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// B2 step 1: raw hits per query position (private_hit_search + find_table_matches,
+// src/seed_search.c:491-571, 810-875, without calling the processor yet)
+__global__ void __launch_bounds__(LZ_TPB)
+k_count_hits(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd,
+             const u32* __restrict__ wstart, u32* __restrict__ cnt, u64* __restrict__ n_words)
+{
+    u32 i = blockIdx.x * LZ_TPB + threadIdx.x;
+    bool valid = false;
+    if (i < hi - lo) {
+        cnt[i] = lz_count_hits_at(qcode, lo + i + 1, lo, sd, wstart, valid);
+    }
+    u64 b = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long*)n_words, (unsigned long long)__popcll(b));
+}
+
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u64* valid_words_dev)
+{
+    u32 n = hi - lo;
+    c.timer.begin("k_count_hits", c.stream);
+    hipLaunchKernelGGL(k_count_hits, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       qcode, lo, hi, c.seed, c.wstart.as<u32>(), cnt, valid_words_dev);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+struct U32ToU64 { __host__ __device__ u64 operator()(u32 x) const { return (u64)x; } };
+
+int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n)
+{
+    auto in = rocprim::make_transform_iterator(cnt, U32ToU64());
+    size_t tmp = 0;
+    LZ_HIP(rocprim::exclusive_scan(nullptr, tmp, in, off, (u64)0, (size_t)n, rocprim::plus<u64>(), c.stream));
+    int rc = c.scan_tmp.ensure(tmp);
+    if (rc) return rc;
+    c.timer.begin("rocprim_scan_counts", c.stream);
+    LZ_HIP(rocprim::exclusive_scan(c.scan_tmp.p, tmp, in, off, (u64)0, (size_t)n, rocprim::plus<u64>(), c.stream));
+    c.timer.end(c.stream);
+    return 0;
+}
+
+// B2 step 2: materialise the hits of query positions [i0,i1) in discovery order
+__global__ void __launch_bounds__(LZ_TPB)
+k_fill_hits(const u8* __restrict__ qcode, u32 lo, u32 i0, u32 i1, LzSeedDev sd,
+            const u32* __restrict__ wstart, const u32* __restrict__ wpos,
+            const u32* __restrict__ cnt, const u64* __restrict__ off, u64 base, u64* __restrict__ keys)
+{
+    u32 i = i0 + blockIdx.x * LZ_TPB + threadIdx.x;
+    if (i >= i1) return;
+    if (cnt[i] == 0) return;
+    lz_fill_hits_at(qcode, lo + i + 1, sd, wstart, wpos, keys + (off[i] - base));
+}
+
+int lzk_fill_hits(LzCtx& c, const u8* qcode, u32 lo, u32 i0, u32 i1, const u32* cnt, const u64* off, u64 base, u64* keys)
+{
+    u32 n = i1 - i0;
+    if (n == 0) return 0;
+    c.timer.begin("k_fill_hits", c.stream);
+    hipLaunchKernelGGL(k_fill_hits, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       qcode, lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), cnt, off, base, keys);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// B2 step 3: stable partition by hashedDiag = key bits 32..47
+int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u64 n)
+{
+    size_t tmp = 0;
+    LZ_HIP(rocprim::radix_sort_keys(nullptr, tmp, keys_in, keys_out, (size_t)n, 32u, 32u + LZ_DIAG_BITS, c.stream));
+    int rc = c.sort_tmp.ensure(tmp);
+    if (rc) return rc;
+    c.timer.begin("rocprim_sort_hits", c.stream);
+    LZ_HIP(rocprim::radix_sort_keys(c.sort_tmp.p, tmp, keys_in, keys_out, (size_t)n, 32u, 32u + LZ_DIAG_BITS, c.stream));
+    c.timer.end(c.stream);
+    return 0;
+}
+
+__global__ void __launch_bounds__(LZ_TPB)
+k_bucket_bounds(const u64* __restrict__ keys, u64 n, u32* __restrict__ bstart)
+{
+    u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
+    if (i > n) return;
+    s32 bp = (i == 0) ? -1 : (s32)((keys[i - 1] >> 32) & (LZ_DIAG_SIZE - 1));
+    s32 b  = (i == n) ? (s32)LZ_DIAG_SIZE : (s32)((keys[i] >> 32) & (LZ_DIAG_SIZE - 1));
+    for (s32 w = bp + 1; w <= b; w++) bstart[w] = (u32)i;
+}
+
+int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart)
+{
+    c.timer.begin("k_bucket_bounds", c.stream);
+    hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n + 1 + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                       keys, n, bstart);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// B2 step 4: one lane per hash bucket
+#define LZ_EXT_TPB 64
+__global__ void __launch_bounds__(LZ_EXT_TPB)
+k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ bstart,
+         u32* __restrict__ diag_end, const s32* __restrict__ score_tab_g,
+         LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap, u64* __restrict__ counters)
+{
+    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
+    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_EXT_TPB) tab[k] = score_tab_g[k];
+    __syncthreads();
+    const u32 h = blockIdx.x * LZ_EXT_TPB + threadIdx.x;
+    const u32 i0 = bstart[h], i1 = bstart[h + 1];
+    u64 n_ext = 0, n_bp = 0;
+    if (i0 < i1) {
+        u32 d = lz_extend_bucket(P, tab, keys, i0, i1, diag_end[h], n_ext, n_bp,
+            [&](const LzHspRec& r) {
+                u32 slot = atomicAdd(out_count, 1u);
+                if (slot < out_cap) out[slot] = r;
+            });
+        diag_end[h] = d;
+    }
+    // wave-level reduction of the work counters
+    for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);
+        if (n_bp)  atomicAdd((unsigned long long*)&counters[1], (unsigned long long)n_bp);
+    }
+}
+
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* bstart, u32* diag_end,
+               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters)
+{
+    c.timer.begin("k_extend", c.stream);
+    hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, c.stream,
+                       P, keys, bstart, diag_end, score_tab, out, out_count, out_cap, counters);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,264 @@
+"""ctypes binding of liblzgpu.so (include/lzgpu.h) for tests and bench.py.
+
+Plumbing only: the product is the C-ABI library.  There is no CPU fallback here -- if the
+library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblzgpu.so")
+
+MAX_PARTS, MAX_PROBES = 16, 128
+
+NH_REASONS = {1: "SEED", 2: "SCORE_CLASSES", 3: "HITS_OVERFLOW", 4: "HSP_OVERFLOW", 5: "SIZE",
+              6: "IDENTICAL", 7: "UNSUPPORTED"}
+
+
+class SeedDesc(C.Structure):
+    _fields_ = [("length", C.c_int32), ("weight_bits", C.c_int32), ("num_parts", C.c_int32),
+                ("shift", C.c_int32 * MAX_PARTS), ("mask", C.c_uint32 * MAX_PARTS),
+                ("num_probes", C.c_int32), ("probe_xor", C.c_uint32 * MAX_PROBES)]
+
+
+class TableGeom(C.Structure):
+    _fields_ = [("tlen", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("step", C.c_uint32),
+                ("num_words", C.c_uint64), ("seed", SeedDesc), ("char_to_bits", C.c_int8 * 256)]
+
+
+class SearchArgs(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("qlen", C.c_uint32), ("query_slot", C.c_int32),
+                ("start", C.c_uint32), ("end", C.c_uint32), ("sub", C.c_void_p),
+                ("xdrop", C.c_int32), ("hsp_threshold", C.c_int32), ("entropic", C.c_int32),
+                ("extend", C.c_int32)]
+
+
+class GappedArgs(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("qlen", C.c_uint32), ("query_slot", C.c_int32),
+                ("sub", C.c_void_p), ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("ydrop", C.c_int32), ("score_thresh", C.c_int32), ("traceback_bytes", C.c_uint32),
+                ("anchors", C.c_void_p), ("n_anchors", C.c_uint32), ("reduce", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("words", C.c_uint64), ("raw_hits", C.c_uint64), ("extensions", C.c_uint64),
+                ("bp_extended", C.c_uint64), ("hsps", C.c_uint64), ("dp_cells", C.c_uint64),
+                ("gapped_extensions", C.c_uint64), ("anchors_extended", C.c_uint64)]
+
+
+HSP_DTYPE = np.dtype([("pos1", "<u4"), ("pos2", "<u4"), ("length", "<u4"), ("score", "<i4")])
+SEG_DTYPE = np.dtype([("pos1", "<u4"), ("pos2", "<u4"), ("length", "<u4"), ("s", "<i4"), ("id", "<i4")])
+ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end2", "<u4"),
+                        ("s", "<i4"), ("script_len", "<u4"), ("script_off", "<u4")])
+
+# every symbol include/lzgpu.h declares (tests check that the library exports all of them)
+EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdown", "lzgpu_free",
+           "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
+           "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_device_copy",
+           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_gapped_extend",
+           "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
+           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity"]
+
+
+class LzGpuError(RuntimeError):
+    pass
+
+
+class NotHandled(Exception):
+    """rc > 0: the library declined; the caller would run the reference CPU routine."""
+    def __init__(self, rc):
+        super().__init__(f"not handled: {NH_REASONS.get(rc, rc)}")
+        self.rc = rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Lib:
+    """One process <-> one GPU.  `prefix`/`path` let tests bind the CPU emulation harness
+    (tests/emul) through the same wrapper; the product always uses the defaults."""
+
+    def __init__(self, path=LIB_PATH, prefix="lzgpu_"):
+        if not os.path.exists(path):
+            raise LzGpuError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        self.L = C.CDLL(path)
+        self.px = prefix
+        f = self._f
+        f("seed_hit_search").argtypes = [C.POINTER(SearchArgs), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        f("table_prepare").argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                       C.POINTER(SeedDesc), C.c_uint32]
+        f("set_hit_capacity").argtypes = [C.c_uint64]
+        f("counters_get").argtypes = [C.POINTER(Counters)]
+        f("free").argtypes = [C.c_void_p]
+        if prefix == "lzgpu_":
+            self.L.lzgpu_seed_from_pattern.argtypes = [C.c_char_p, C.c_int, C.POINTER(SeedDesc)]
+            self.L.lzgpu_last_error.restype = C.c_char_p
+            self.L.lzgpu_table_num_words.restype = C.c_uint64
+            self.L.lzgpu_table_export.argtypes = [C.c_void_p, C.c_void_p]
+            self.L.lzgpu_table_geom.argtypes = [C.POINTER(TableGeom)]
+            self.L.lzgpu_table_adopt.argtypes = [C.POINTER(TableGeom)]
+            self.L.lzgpu_table_buffers.argtypes = [C.POINTER(C.c_void_p * 3), C.POINTER(C.c_uint64 * 3)]
+            self.L.lzgpu_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+            self.L.lzgpu_query_upload.argtypes = [C.c_int32, C.c_void_p, C.c_uint32]
+            self.L.lzgpu_gapped_extend.argtypes = [C.POINTER(GappedArgs), C.POINTER(C.c_void_p),
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                                   C.POINTER(C.c_uint64)]
+            self.L.lzgpu_set_hsp_capacity.argtypes = [C.c_uint64]
+            self.L.lzgpu_profile_get.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_double)]
+        self._keep = {}
+
+    def _f(self, name):
+        return getattr(self.L, self.px + name)
+
+    def _check(self, rc, what):
+        if rc > 0:
+            raise NotHandled(rc)
+        if rc < 0:
+            msg = self.L.lzgpu_last_error().decode() if self.px == "lzgpu_" else ""
+            raise LzGpuError(f"{what} failed rc={rc}: {msg}")
+
+    # ---- lifecycle
+    def init(self, device=-1):
+        self._check(self.L.lzgpu_init(device), "lzgpu_init")
+
+    def probe(self):
+        return self.L.lzgpu_probe()
+
+    def shutdown(self):
+        self.L.lzgpu_shutdown()
+
+    # ---- seeds
+    def seed(self, pattern="1110100110010101111", with_trans=1):
+        sd = SeedDesc()
+        fn = self.L.lzgpu_seed_from_pattern      # (the emulation harness links the same lz_host.cpp)
+        fn.argtypes = [C.c_char_p, C.c_int, C.POINTER(SeedDesc)]
+        rc = fn(pattern.encode(), with_trans, C.byref(sd))
+        self._check(rc, "lzgpu_seed_from_pattern")
+        return sd
+
+    # ---- B1
+    def table_prepare(self, t, sd, char_to_bits, step=1, start=0, end=0):
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        ctb = np.ascontiguousarray(char_to_bits, dtype=np.int8)
+        self._keep["ctb"] = ctb
+        self._check(self._f("table_prepare")(_ptr(t), len(t), start, end, _ptr(ctb), C.byref(sd), step),
+                    "lzgpu_table_prepare")
+        self._weight = sd.weight_bits
+
+    def table_rebuild(self):
+        self._check(self.L.lzgpu_table_rebuild(), "lzgpu_table_rebuild")
+
+    def table_num_words(self):
+        return int(self.L.lzgpu_table_num_words())
+
+    def table_export(self, prev_entries):
+        last = np.zeros(1 << self._weight, dtype=np.uint32)
+        prev = np.zeros(prev_entries, dtype=np.uint32)
+        self._check(self.L.lzgpu_table_export(_ptr(last), _ptr(prev)), "lzgpu_table_export")
+        return last, prev
+
+    def table_geom(self):
+        g = TableGeom()
+        self._check(self.L.lzgpu_table_geom(C.byref(g)), "lzgpu_table_geom")
+        return g
+
+    def table_adopt(self, g):
+        self._check(self.L.lzgpu_table_adopt(C.byref(g)), "lzgpu_table_adopt")
+        self._weight = g.seed.weight_bits
+
+    def table_buffers(self):
+        p = (C.c_void_p * 3)()
+        b = (C.c_uint64 * 3)()
+        self._check(self.L.lzgpu_table_buffers(C.byref(p), C.byref(b)), "lzgpu_table_buffers")
+        return [(int(p[i] or 0), int(b[i])) for i in range(3)]
+
+    def device_copy(self, dst, src, nbytes):
+        self._check(self.L.lzgpu_device_copy(dst, src, nbytes), "lzgpu_device_copy")
+
+    def table_commit(self):
+        self._check(self.L.lzgpu_table_commit(), "lzgpu_table_commit")
+
+    # ---- B2
+    def query_upload(self, slot, q):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        self._check(self.L.lzgpu_query_upload(slot, _ptr(q), len(q)), "lzgpu_query_upload")
+        self._keep[("qlen", slot)] = len(q)
+
+    def seed_hit_search(self, sub, q=None, slot=-1, xdrop=910, hsp_threshold=3000, entropic=True,
+                        extend=True, start=0, end=0):
+        a = SearchArgs()
+        sub = np.ascontiguousarray(sub, dtype=np.int32)
+        if q is not None:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            a.query, a.qlen = q.ctypes.data, len(q)
+        else:
+            a.query, a.qlen = None, self._keep[("qlen", slot)]
+        a.query_slot, a.start, a.end = slot, start, end
+        a.sub, a.xdrop, a.hsp_threshold = sub.ctypes.data, xdrop, hsp_threshold
+        a.entropic, a.extend = int(entropic), int(extend)
+        out = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self._f("seed_hit_search")(C.byref(a), C.byref(out), C.byref(n)), "lzgpu_seed_hit_search")
+        res = np.zeros(n.value, dtype=HSP_DTYPE)
+        if n.value:
+            C.memmove(_ptr(res), out, n.value * HSP_DTYPE.itemsize)
+        self._f("free")(out)
+        return res
+
+    # ---- B3
+    def gapped_extend(self, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400,
+                      score_thresh=3000, traceback_bytes=0, reduce=True):
+        a = GappedArgs()
+        sub = np.ascontiguousarray(sub, dtype=np.int32)
+        anchors = np.ascontiguousarray(anchors.copy(), dtype=SEG_DTYPE)
+        if q is not None:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            a.query, a.qlen = q.ctypes.data, len(q)
+        else:
+            a.query, a.qlen = None, self._keep[("qlen", slot)]
+        a.query_slot = slot
+        a.sub, a.gap_open, a.gap_extend, a.ydrop = sub.ctypes.data, gap_open, gap_extend, ydrop
+        a.score_thresh, a.traceback_bytes = score_thresh, traceback_bytes
+        a.anchors, a.n_anchors, a.reduce = anchors.ctypes.data, len(anchors), int(reduce)
+        out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
+        self._check(self.L.lzgpu_gapped_extend(C.byref(a), C.byref(out), C.byref(n), C.byref(ops), C.byref(nops)),
+                    "lzgpu_gapped_extend")
+        al = np.zeros(n.value, dtype=ALIGN_DTYPE)
+        op = np.zeros(nops.value, dtype=np.uint32)
+        if n.value:
+            C.memmove(_ptr(al), out, n.value * ALIGN_DTYPE.itemsize)
+        if nops.value:
+            C.memmove(_ptr(op), ops, nops.value * 4)
+        self.L.lzgpu_free(out); self.L.lzgpu_free(ops)
+        return al, op
+
+    # ---- instrumentation
+    def counters_reset(self):
+        self._f("counters_reset")()
+
+    def counters(self):
+        c = Counters()
+        self._f("counters_get")(C.byref(c))
+        return {k: int(getattr(c, k)) for k, _ in Counters._fields_}
+
+    def set_hit_capacity(self, n):
+        self._check(self._f("set_hit_capacity")(n), "set_hit_capacity")
+
+    def profile_enable(self, on=True):
+        self.L.lzgpu_profile_enable(int(on))
+
+    def profile_reset(self):
+        self.L.lzgpu_profile_reset()
+
+    def profile(self):
+        out, i = {}, 0
+        while True:
+            name = C.c_char_p(); n = C.c_uint64(); ms = C.c_double()
+            if self.L.lzgpu_profile_get(i, C.byref(name), C.byref(n), C.byref(ms)):
+                break
+            out[name.value.decode()] = {"launches": int(n.value), "ms": float(ms.value)}
+            i += 1
+        return out

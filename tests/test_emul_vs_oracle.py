@@ -1,0 +1,87 @@
+"""CPU check of the GPU pipeline's DECOMPOSITION: tests/emul runs the very per-lane functions the
+kernels execute (lastz_amd/csrc/lz_common.hpp) plus the product's host pieces (lz_host.cpp),
+serially, in the device pipeline's order (count/scan/fill, stable bucket partition, one lane per
+bucket, host finish) and must reproduce the oracle bit for bit -- HSPs, order and work counters.
+The emulation is test infrastructure, not a fallback."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from oracle import lzo
+from lastz_amd import seqio, lzgpu
+import helpers as H
+
+EMUL_DIR = os.path.join(H.ROOT, "tests", "emul")
+
+
+@pytest.fixture(scope="module")
+def em():
+    so = os.path.join(EMUL_DIR, "libemul.so")
+    srcs = [os.path.join(EMUL_DIR, "emul_seed.cpp"), os.path.join(H.ROOT, "lastz_amd", "csrc", "lz_host.cpp")]
+    deps = srcs + [os.path.join(H.ROOT, "lastz_amd", "csrc", f) for f in ("lz_common.hpp", "lz_host.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+    return lzgpu.Lib(path=so, prefix="emul_")
+
+
+def _check(em, t, q, pattern=H.DEFAULT_SEED, wt=1, cap=None, step=1, **kw):
+    _, masked = H.scoring()
+    ctb = lzo.upper_nuc_to_bits()
+    osd = lzo.seed(pattern, wt)
+    tab = lzo.Table(t, osd, step=step)
+    sd = em.seed(pattern, wt)
+    assert [sd.probe_xor[i] for i in range(sd.num_probes)] == [osd.probe_xor[i] for i in range(osd.num_probes)]
+    em.table_prepare(t, sd, ctb, step=step)
+    ws, wp = tab.csr()
+    ews = np.zeros(len(ws), dtype=np.uint32); ewp = np.zeros(max(len(wp), 1), dtype=np.uint32)
+    n = em.L.emul_table_csr(C.c_void_p(ews.ctypes.data), C.c_void_p(ewp.ctypes.data))
+    assert n == len(wp) and (ews == ws).all() and (ewp[:n] == wp).all()
+    em.set_hit_capacity(cap or (1 << 28))
+    for _, _, qq in H.strands(q):
+        for mode in (0, 1):
+            ho, st = lzo.seed_hit_search(tab, qq, masked, mode=mode, **kw)
+            em.counters_reset()
+            he = em.seed_hit_search(masked, q=qq, extend=(mode == 0), **kw)
+            c = em.counters()
+            assert len(ho) == len(he) and (ho == he).all()
+            assert c["words"] == st["words"] and c["raw_hits"] == st["raw_hits"]
+            if mode == 0:
+                assert all(c[k] == st[k] for k in ("extensions", "bp_extended", "hsps"))
+
+
+def test_reference_inputs(em):
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+    for _, q in seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa")):
+        _check(em, tgt, q)
+        _check(em, tgt, q, cap=1024)                       # many chunks: diagEnd carried across chunks
+        _check(em, tgt, q, pattern="11111111", wt=0)
+
+
+@pytest.mark.parametrize("case,cap", [("synth200k", 20000), ("synth_overlap", 1 << 28), ("adversarial", 5000)])
+def test_golden_cases(em, case, cap):
+    t, q = H.load_case(case)
+    _check(em, t, q, cap=cap)
+
+
+def test_seeds_steps_thresholds(em):
+    t, q = seqio.synth_pair(60000, 50000, seed=31, block_min=500, block_max=4000)
+    _check(em, t, q, pattern="111101101111", wt=1, step=3)
+    _check(em, t, q, pattern="11111111", wt=2, hsp_threshold=2000, xdrop=500)
+    _check(em, t, q, pattern="1111111111", wt=0, entropic=False, cap=4096)
+
+
+def test_chunk_planner_splits_inside_a_block(em):
+    # a 9-mer exact seed on a low-complexity target: single query positions carry many hits
+    rng = np.random.default_rng(5)
+    unit = np.frombuffer(b"ACGTACGGTACC", dtype=np.uint8)
+    t = np.tile(unit, 400)
+    q = np.concatenate([np.tile(unit, 30), np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 500)]])
+    _check(em, t, q, pattern="111111111", wt=0, cap=1024, hsp_threshold=1000)
+    _, masked = H.scoring()
+    em.set_hit_capacity(1024)
+    sd = em.seed("111111111", 0)
+    em.table_prepare(np.tile(unit, 4000), sd, lzo.upper_nuc_to_bits())
+    with pytest.raises(lzgpu.NotHandled):                  # one position alone exceeds the capacity
+        em.seed_hit_search(masked, q=q)

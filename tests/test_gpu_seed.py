@@ -1,0 +1,208 @@
+"""Parity tests proper for the seed stage (B1 + B2): the HIP path, called through the C ABI,
+against the oracle / the reference's golden vectors.  Bit-exact: integer scores, coordinates,
+order and work counters.  Needs an MI355X."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+from oracle import lzo
+from lastz_amd import seqio, lzgpu
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+CTB = lzo.upper_nuc_to_bits()
+
+
+def _prep(gpu, t, pattern=H.DEFAULT_SEED, wt=1, step=1, start=0, end=0):
+    sd = gpu.seed(pattern, wt)
+    gpu.table_prepare(t, sd, CTB, step=step, start=start, end=end)
+    return lzo.Table(t, lzo.seed(pattern, wt), step=step, start=start, end=end)
+
+
+def _same_hsps(gpu, tab, qq, masked, **kw):
+    gpu.counters_reset()
+    got = gpu.seed_hit_search(masked, q=qq, **kw)
+    okw = dict(kw)
+    mode = 0 if okw.pop("extend", True) else 1
+    want, st = lzo.seed_hit_search(tab, qq, masked, mode=mode, **okw)
+    assert len(got) == len(want)
+    assert (got == want).all()
+    c = gpu.counters()
+    assert c["words"] == st["words"] and c["raw_hits"] == st["raw_hits"]
+    if mode == 0:
+        assert c["extensions"] == st["extensions"] and c["bp_extended"] == st["bp_extended"] and c["hsps"] == st["hsps"]
+    return got
+
+
+@pytest.mark.parametrize("pattern,wt,step,start,end", [(H.DEFAULT_SEED, 1, 1, 0, 0), ("11111111", 0, 1, 0, 0),
+                                                        ("111101101111", 1, 3, 0, 0), (H.DEFAULT_SEED, 1, 1, 1000, 15000),
+                                                        ("1111111111", 0, 25, 7, 18000)])
+def test_position_table_matches_reference_layout(gpu, pattern, wt, step, start, end):
+    """B1: device CSR table, exported in the reference's last[]/prev[] layout, equals the oracle's
+    restatement of build_seed_position_table (which is pinned against the reference)."""
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1].copy()
+    tgt[5000:5040] = ord("N"); tgt[9000:9100] |= 0x20           # bytes that break words
+    tab = _prep(gpu, tgt, pattern, wt, step, start, end)
+    pt = tab.pt.contents
+    assert gpu.table_num_words() == pt.words_in_table
+    last, prev = gpu.table_export(pt.prev_entries)
+    assert (last == np.ctypeslib.as_array(pt.last, shape=(pt.word_entries,))).all()
+    assert (prev == np.ctypeslib.as_array(pt.prev, shape=(pt.prev_entries,))).all()
+
+
+def test_reference_goldens_hits_and_hsps(gpu):
+    """base_test.hits.lav (raw hits, plain processor) and base_test.hsp.lav (X-drop HSPs)"""
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+    qs = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))
+    _, masked = H.scoring()
+    _prep(gpu, tgt, "11111111", 0)
+    gold_hits = H.lav_blocks(os.path.join(H.GOLDEN, "base_test.hits.lav"))
+    gold_hsp = H.lav_blocks(os.path.join(H.GOLDEN, "base_test.hsp.lav"))
+    mine = []
+    for ci, (_, q) in enumerate(qs):
+        hits = gpu.seed_hit_search(masked, q=q, extend=False)
+        assert [((int(h["pos1"]) - 7, int(h["pos2"]) - 7), (int(h["pos1"]), int(h["pos2"]))) for h in hits] == \
+               [(b["b"], b["e"]) for b in gold_hits[ci][2]]
+        for _, rev, qq in H.strands(q):
+            hsps = gpu.seed_hit_search(masked, q=qq)
+            if len(hsps):
+                mine.append((ci + 1, rev, [(int(h["score"]), int(h["pos1"] - h["length"]) + 1, int(h["pos2"] - h["length"]) + 1,
+                                            int(h["pos1"]), int(h["pos2"])) for h in hsps]))
+    assert mine == [(c, r, [(b["score"],) + b["b"] + b["e"] for b in bl]) for c, r, bl in gold_hsp]
+
+
+@pytest.mark.parametrize("case,cap", [("synth200k", None), ("synth200k", 30000), ("synth_overlap", None), ("adversarial", 4096)])
+def test_golden_cases_against_reference_output(gpu, case, cap):
+    """HSP rows and collect_stats counters produced by the pristine reference (tests/golden)"""
+    t, q = H.load_case(case)
+    _, masked = H.scoring()
+    _prep(gpu, t)
+    gpu.set_hit_capacity(cap or (1 << 28))
+    gold = H.read_hsp_tsv(os.path.join(H.GOLDEN, case + ".hsp.tsv"))
+    gst = H.load_stats(case)
+    rows = []
+    gpu.counters_reset()
+    for strand, _, qq in H.strands(q):
+        rows += H.hsps_as_tsv_rows("query", strand, gpu.seed_hit_search(masked, q=qq))
+    gpu.set_hit_capacity(1 << 28)
+    assert rows == gold
+    c = gpu.counters()
+    for k in ("words", "raw_hits", "extensions", "bp_extended", "hsps"):
+        assert c[k] == gst[k], k
+
+
+def test_seeds_steps_thresholds_vs_oracle(gpu):
+    t, q = seqio.synth_pair(120000, 90000, seed=31, block_min=500, block_max=4000)
+    _, masked = H.scoring()
+    for pattern, wt, step, kw in [("111101101111", 1, 3, {}), ("11111111", 2, 1, dict(hsp_threshold=2000, xdrop=500)),
+                                  ("1111111111", 0, 1, dict(entropic=False)), (H.DEFAULT_SEED, 0, 1, dict(extend=False))]:
+        tab = _prep(gpu, t, pattern, wt, step)
+        for _, _, qq in H.strands(q):
+            _same_hsps(gpu, tab, qq, masked, **kw)
+
+
+def test_edge_cases(gpu):
+    _, masked = H.scoring()
+    t, q = seqio.synth_pair(30000, 30000, seed=9)
+    tab = _prep(gpu, t)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    assert len(gpu.seed_hit_search(masked, q=acgt[[0, 1, 2]])) == 0          # shorter than the seed
+    assert len(gpu.seed_hit_search(masked, q=np.full(5000, ord("N"), np.uint8))) == 0
+    _same_hsps(gpu, tab, q | 0x20, masked)                                    # all lower case
+    _same_hsps(gpu, tab, q, masked, start=1234, end=20001)                    # sub-interval of the query
+    q2 = q.copy(); q2[::97] = ord("N"); q2[5000:5600] |= 0x20
+    _same_hsps(gpu, tab, q2, masked)
+    # ragged: query much shorter / longer than the target, target == tiny
+    _same_hsps(gpu, tab, q[:200], masked)
+    tab2 = _prep(gpu, t[:100])
+    _same_hsps(gpu, tab2, q, masked)
+    # a seed hit at the very ends of both sequences
+    tab3 = _prep(gpu, t)
+    q3 = np.concatenate([t[:40], q[:5000], t[-40:]])
+    _same_hsps(gpu, tab3, q3, masked, hsp_threshold=1500)
+
+
+def test_diag_hash_collisions_and_long_hsps(gpu):
+    """tandem repeats: thousands of hits per hashed diagonal, clipped left extensions"""
+    t, q = H.load_case("adversarial")
+    _, masked = H.scoring()
+    big_t = np.concatenate([t, seqio.synth_pair(140000, 10, seed=1)[0], t[::-1].copy()])   # > 65536 apart copies
+    tab = _prep(gpu, big_t)
+    for _, _, qq in H.strands(np.concatenate([q, q])):
+        _same_hsps(gpu, tab, qq, masked)
+
+
+def test_two_mbp_pair_and_capacity_invariance(gpu):
+    t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=12)
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    for _, _, qq in H.strands(q):
+        a = _same_hsps(gpu, tab, qq, masked)
+        gpu.set_hit_capacity(300000)
+        b = gpu.seed_hit_search(masked, q=qq)
+        gpu.set_hit_capacity(1 << 28)
+        assert (a == b).all()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json config 2 size class (scaled to keep the GPU tier short): properties that do not
+    need the oracle -- determinism, chunk-capacity invariance, every HSP re-scores to its score on
+    the host, HSPs arrive in discovery-compatible order, counters obey H >= E >= HSPs."""
+    t, q = seqio.synth_pair(20_000_000, 20_000_000, seed=4)
+    sub, masked = H.scoring()
+    _prep(gpu, t)
+    gpu.counters_reset()
+    a = gpu.seed_hit_search(masked, q=q)
+    c = gpu.counters()
+    gpu.set_hit_capacity(1 << 26)
+    b = gpu.seed_hit_search(masked, q=q)
+    gpu.set_hit_capacity(1 << 28)
+    assert len(a) > 1000 and (a == b).all()
+    assert c["raw_hits"] >= c["extensions"] >= c["hsps"] == len(a)
+    assert c["words"] == len(q) - 18
+    # expected random hits ~ 13 * T * Q / 2^24; within 10 %
+    model = 13.0 * len(t) * len(q) / 2 ** 24
+    assert 0.9 * model < c["raw_hits"] < 1.3 * model
+    rng = np.random.default_rng(0)
+    for h in a[rng.integers(0, len(a), 300)]:
+        s1, s2, n = int(h["pos1"] - h["length"]), int(h["pos2"] - h["length"]), int(h["length"])
+        raw = int(masked[t[s1:s1 + n], q[s2:s2 + n]].sum())
+        assert raw >= h["score"] >= 3000                      # entropy only ever lowers a score
+        if raw > 9000:
+            assert raw == h["score"]
+
+
+@pytest.mark.skipif(lzo.ref_binary() is None, reason="oracle/_ref/lastz not present")
+def test_live_against_reference_binary(gpu, tmp_path):
+    """same run, same inputs: the pristine reference binary vs the HIP path"""
+    t, q = seqio.synth_pair(1_000_000, 1_000_000, seed=77)
+    tf, qf = str(tmp_path / "t.fa"), str(tmp_path / "q.fa")
+    seqio.write_fasta(tf, [("target", t)]); seqio.write_fasta(qf, [("query", q)])
+    out = H.ref_run([tf, qf, "--nogapped", "--format=general-:name2,start1,end1,start2,end2,strand2,score"])
+    gold = [(f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), f[5], int(f[6]))
+            for f in (ln.split("\t") for ln in out.split("\n") if ln)]
+    _, masked = H.scoring()
+    _prep(gpu, t)
+    rows = []
+    for strand, _, qq in H.strands(q):
+        rows += H.hsps_as_tsv_rows("query", strand, gpu.seed_hit_search(masked, q=qq))
+    assert rows == gold
+
+
+def test_resident_query_slots_and_torch_first_process(gpu):
+    """bench.py's mode: queries resident in HBM; and the library loaded AFTER torch (so that it binds
+    the HIP runtime torch brought in), in a fresh process."""
+    t, q = H.load_case("synth200k")
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    gpu.query_upload(0, q); gpu.query_upload(1, seqio.revcomp(q))
+    for slot, (_, _, qq) in enumerate(H.strands(q)):
+        want, _ = lzo.seed_hit_search(tab, qq, masked)
+        got = gpu.seed_hit_search(masked, slot=slot)
+        assert (got == want).all()
+    code = ("import torch, sys; sys.path.insert(0, %r); import __graft_entry__ as g; "
+            "torch.cuda.init(); g.smoke()" % H.ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
