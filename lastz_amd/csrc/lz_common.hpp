@@ -74,9 +74,8 @@ LZ_HD bool lz_window_word(const u8* code, u32 pos, const LzSeedDev& sd, u32& pac
 
 // Number of raw seed hits the query word ending at pos2 generates: the sum over probes of the
 // CSR list length (find_table_matches, src/seed_search.c:823-832).
-LZ_HD u32 lz_count_hits_at(const u8* qcode, u32 pos2, u32 lo, const LzSeedDev& sd, const u32* wstart, bool& valid)
+LZ_HD u32 lz_count_hits_at(const u8* qcode, u32 pos2, u32 lo, const LzSeedDev& sd, const u32* wstart, bool& valid, u32& packed)
 {
-    u32 packed;
     valid = false;
     if (pos2 < lo + (u32)sd.length) return 0;            // window must start at or after the interval start
     if (!lz_window_word(qcode, pos2, sd, packed)) return 0;
@@ -111,61 +110,117 @@ struct LzExtendParams {
     u32 seed_len;
 };
 
+struct LzVec16 { u32 w[4]; };
+// 16 consecutive code bytes from an arbitrary (unaligned) address: one global_load_dwordx4 on
+// gfx950 (amdhsa enables unaligned access mode); the sequences carry LZ_SEQ_PAD readable bytes on
+// both sides so a block may overhang either end.
+LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); return v; }
+#define LZ_VBYTE(v, k) (((v).w[(k) >> 2] >> (((k) & 3) * 8)) & 0xFFu)
+
 // One bucket (= one value of hashedDiag) of the diagonal hash: process its hits of this chunk
 // in enumeration order.  This is process_for_simple_hit + xdrop_extend_seed_hit
 // (src/seed_search.c:1056-1192, 2528-2959) with diagEnd[h] held in a register.
 //   keys[i0..i1)  this bucket's hits, already in discovery order
 //   dend          diagEnd[h] on entry (0 == inactive, src/seed_search.c:1097-1111)
 // Returns the updated diagEnd[h].  emit(rec) is called for every extension scoring >= min_score.
+//
+// Shape: ONE flat loop per lane.  Each trip either starts the lane's next hit or advances the
+// current hit by one 16-base block on the left AND on the right (the two X-drop scans of the
+// reference are independent of each other: loop 2 restarts from the seed end with runScore=0,
+// :2663-2682), so the lanes of a wave never wait for each other per hit, the two serial
+// score chains give each lane 2-way ILP, and every memory access is a 16-byte load whose 16
+// score look-ups are issued together.  The per-base semantics are exactly the reference's:
+// the X-drop test "run >= best - xDrop" gates each further base (:2623, :2684).
 template <class Emit>
 LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*32]*/,
                            const u64* keys, u32 i0, u32 i1, u32 dend,
                            u64& n_ext, u64& n_bp, Emit&& emit)
 {
     const u32 L = P.seed_len;
-    for (u32 i = i0; i < i1; i++) {
-        const u64 key = keys[i];
-        const u32 pos2 = (u32)key;
-        const s32 diag = (s32)(u32)(key >> 32);
-        const u32 pos1 = pos2 + (u32)diag;
-        if (dend > pos2 - L) continue;                          // :1113
+    const s32 xd = P.xdrop;
+    u32 i = i0;
+    bool in_hit = false;
+    u32 pos1 = 0, pos2 = 0, sl = 0, sr = 0, left_start = 0, right_stop = 0;
+    s32 diag = 0, stopl = 0, stopr = 0, runl = 0, bestl = 0, runr = 0, bestr = 0;
+    bool alive_l = false, alive_r = false;
 
-        n_ext++;
-        // left extension, :2612-2632
-        s32 stopl = (s32)dend + diag;  if (stopl < 0) stopl = 0;
-        u32 s1 = pos1, left_start = pos1;
-        s32 run = 0, left = 0;
-        {
-            const u8* tp = P.tcode; const u8* qp = P.qcode;
-            while ((s32)s1 > stopl && run >= left - P.xdrop) {
-                --s1;
-                run += score_tab[(LZ_CODE_CLASS(tp[s1]) << 5) | LZ_CODE_CLASS(qp[(s32)s1 - diag])];
-                if (run > left) { left = run; left_start = s1; }
-            }
+    for (;;) {
+        if (!in_hit) {
+            if (i >= i1) break;
+            const u64 key = keys[i++];
+            pos2 = (u32)key;
+            diag = (s32)(u32)(key >> 32);
+            pos1 = pos2 + (u32)diag;
+            if (dend > pos2 - L) continue;                      // :1113
+            n_ext++;
+            stopl = (s32)dend + diag;  if (stopl < 0) stopl = 0;                               // :2612-2616
+            stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
+            sl = sr = left_start = right_stop = pos1;
+            runl = bestl = runr = bestr = 0;
+            alive_l = ((s32)sl > stopl) && (0 >= -xd);
+            alive_r = ((s32)sr < stopr) && (0 >= -xd);
+            in_hit = true;
         }
-        const u32 left_block = s1;
-        // right extension, :2675-2694
-        s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
-        s1 = pos1; u32 right_stop = pos1;
-        s32 right = 0; run = 0;
-        {
-            const u8* tp = P.tcode; const u8* qp = P.qcode;
-            while ((s32)s1 < stopr && run >= right - P.xdrop) {
-                run += score_tab[(LZ_CODE_CLASS(tp[s1]) << 5) | LZ_CODE_CLASS(qp[(s32)s1 - diag])];
-                s1++;
-                if (run > right) { right = run; right_stop = s1; }
+        if (alive_l) {                                          // loop 1, :2623-2632, 16 bases
+            const u32 room = (u32)((s32)sl - stopl);
+            const LzVec16 tv = lz_load16(P.tcode + sl - 16);
+            const LzVec16 qv = lz_load16(P.qcode + ((s32)sl - diag) - 16);
+            s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, 15 - k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, 15 - k))];
+            bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++) {
+                if (go && (u32)k < room) {
+                    runl += sc[k];
+                    --sl;
+                    if (runl > bestl) { bestl = runl; left_start = sl; }
+                    go = runl >= bestl - xd;
+                }
             }
+            alive_l = go && ((s32)sl > stopl);
         }
-        const u32 extent = (u32)((s32)s1 - diag);               // :2785
-        if (extent > dend) dend = extent;
-        n_bp += (u64)(s1 - left_block);                         // :2818
-
-        const s32 sim = left + right;
-        if (sim >= P.min_score) {
-            LzHspRec r;
-            r.seed_pos1 = pos1; r.seed_pos2 = pos2;
-            r.end1 = right_stop; r.length = right_stop - left_start; r.score = sim;
-            emit(r);
+        if (alive_r) {                                          // loop 2, :2684-2693, 16 bases
+            const u32 room = (u32)(stopr - (s32)sr);
+            const LzVec16 tv = lz_load16(P.tcode + sr);
+            const LzVec16 qv = lz_load16(P.qcode + ((s32)sr - diag));
+            s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, k))];
+            bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++) {
+                if (go && (u32)k < room) {
+                    runr += sc[k];
+                    ++sr;
+                    if (runr > bestr) { bestr = runr; right_stop = sr; }
+                    go = runr >= bestr - xd;
+                }
+            }
+            alive_r = go && ((s32)sr < stopr);
+        }
+        if (!alive_l && !alive_r) {                             // both scans have stopped
+            const u32 extent = (u32)((s32)sr - diag);           // :2785 (where loop 2 STOPPED)
+            if (extent > dend) dend = extent;
+            n_bp += (u64)(sr - sl);                             // :2818
+            const s32 sim = bestl + bestr;
+            if (sim >= P.min_score) {
+                LzHspRec r;
+                r.seed_pos1 = pos1; r.seed_pos2 = pos2;
+                r.end1 = right_stop; r.length = right_stop - left_start; r.score = sim;
+                emit(r);
+            }
+            in_hit = false;
         }
     }
     return dend;

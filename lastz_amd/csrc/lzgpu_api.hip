@@ -118,7 +118,7 @@ extern "C" void lzgpu_shutdown(void)
     if (!c.inited) return;
     (void)hipStreamSynchronize(c.stream);
     c.timer.resolve();
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.keys_a, &c.keys_b,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b,
                        &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
@@ -338,6 +338,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     const u32 n = hi - lo;
     if ((rc = c.cnt.ensure((size_t)n * 4))) return rc;
     if ((rc = c.off.ensure((size_t)n * 8))) return rc;
+    if ((rc = c.pk.ensure((size_t)n * 4))) return rc;
     if ((rc = c.bstart.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
     if ((rc = c.diag_end.ensure((size_t)LZ_DIAG_SIZE * 4))) return rc;
     if ((rc = c.dev_counters.ensure(8 * 8))) return rc;
@@ -348,7 +349,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     u64* d_counters = c.dev_counters.as<u64>();                 // [0]=extensions [1]=bp [2]=words
 
     // ---- 1. count + scan
-    if ((rc = lzk_count_hits(c, qs->code_base(), lo, hi, c.cnt.as<u32>(), d_counters + 2))) return rc;
+    if ((rc = lzk_count_hits(c, qs->code_base(), lo, hi, c.cnt.as<u32>(), c.pk.as<u32>(), d_counters + 2))) return rc;
     if ((rc = lzk_scan_counts(c, c.cnt.as<u32>(), c.off.as<u64>(), n))) return rc;
 
     u64 last_off = 0; u32 last_cnt = 0;
@@ -395,7 +396,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     std::vector<lz_hsp> plain;
     // ---- 3. per chunk: fill -> (stable bucket sort -> bounds -> bucket-serial extension)
     for (auto& ch : chunks) {
-        if ((rc = lzk_fill_hits(c, qs->code_base(), lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
+        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.pk.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
             std::vector<u64> hk(ch.nh);
             LZ_HIP(hipMemcpyAsync(hk.data(), c.keys_a.p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));

@@ -163,23 +163,26 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries)
 // src/seed_search.c:491-571, 810-875, without calling the processor yet)
 __global__ void __launch_bounds__(LZ_TPB)
 k_count_hits(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd,
-             const u32* __restrict__ wstart, u32* __restrict__ cnt, u64* __restrict__ n_words)
+             const u32* __restrict__ wstart, u32* __restrict__ cnt, u32* __restrict__ pk,
+             u64* __restrict__ n_words)
 {
     u32 i = blockIdx.x * LZ_TPB + threadIdx.x;
     bool valid = false;
     if (i < hi - lo) {
-        cnt[i] = lz_count_hits_at(qcode, lo + i + 1, lo, sd, wstart, valid);
+        u32 packed = 0;
+        cnt[i] = lz_count_hits_at(qcode, lo + i + 1, lo, sd, wstart, valid, packed);
+        pk[i] = packed;                                  // only read where cnt[i] > 0
     }
     u64 b = __ballot(valid);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long*)n_words, (unsigned long long)__popcll(b));
 }
 
-int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u64* valid_words_dev)
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u64* valid_words_dev)
 {
     u32 n = hi - lo;
     c.timer.begin("k_count_hits", c.stream);
     hipLaunchKernelGGL(k_count_hits, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
-                       qcode, lo, hi, c.seed, c.wstart.as<u32>(), cnt, valid_words_dev);
+                       qcode, lo, hi, c.seed, c.wstart.as<u32>(), cnt, pk, valid_words_dev);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -200,25 +203,52 @@ int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n)
     return 0;
 }
 
-// B2 step 2: materialise the hits of query positions [i0,i1) in discovery order
+// B2 step 2: materialise the hits of query positions [i0,i1) in discovery order.
+// 16 lanes per query position, one probe (exact word / transition flip) per lane: each lane reads
+// its word's CSR range, a 16-lane prefix sum places the probes' lists back to back in probe order
+// (= the reference's enumeration order within a position, src/seed_search.c:522-549), and the 4
+// positions of a wave write one contiguous window of the hit array.
+#define LZ_FILL_GROUP 16
 __global__ void __launch_bounds__(LZ_TPB)
-k_fill_hits(const u8* __restrict__ qcode, u32 lo, u32 i0, u32 i1, LzSeedDev sd,
+k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
-            const u32* __restrict__ cnt, const u64* __restrict__ off, u64 base, u64* __restrict__ keys)
+            const u32* __restrict__ cnt, const u32* __restrict__ pk, const u64* __restrict__ off,
+            u64 base, u64* __restrict__ keys)
 {
-    u32 i = i0 + blockIdx.x * LZ_TPB + threadIdx.x;
-    if (i >= i1) return;
-    if (cnt[i] == 0) return;
-    lz_fill_hits_at(qcode, lo + i + 1, sd, wstart, wpos, keys + (off[i] - base));
+    const u32 gid = (blockIdx.x * LZ_TPB + threadIdx.x) / LZ_FILL_GROUP;
+    const u32 p   = threadIdx.x & (LZ_FILL_GROUP - 1);
+    const u32 i   = i0 + gid;
+    const bool have = (i < i1) && (cnt[i] != 0);        // uniform across the 16-lane group
+    const u32 packed = have ? pk[i] : 0;
+    const u32 pos2 = lo + i + 1;
+    u64* out = have ? keys + (off[i] - base) : keys;
+    u32 carry = 0;
+    for (int r = 0; r < sd.nprobes; r += LZ_FILL_GROUP) {   // uniform trip count
+        u32 a = 0, len = 0;
+        if (have && r + (int)p < sd.nprobes) {
+            const u32 w = packed ^ sd.probe_xor[r + p];
+            a = wstart[w]; len = wstart[w + 1] - a;
+        }
+        u32 incl = len;                                  // inclusive prefix over the 16-lane group
+#pragma unroll
+        for (int d = 1; d < LZ_FILL_GROUP; d <<= 1) {
+            u32 v = __shfl_up(incl, d, LZ_FILL_GROUP);
+            if ((int)p >= d) incl += v;
+        }
+        const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
+        u64* o = out + carry + (incl - len);
+        for (u32 j = 0; j < len; j++) o[j] = lz_hit_key(wpos[a + j], pos2);
+        carry += total;
+    }
 }
 
-int lzk_fill_hits(LzCtx& c, const u8* qcode, u32 lo, u32 i0, u32 i1, const u32* cnt, const u64* off, u64 base, u64* keys)
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys)
 {
-    u32 n = i1 - i0;
+    u64 n = (u64)(i1 - i0) * LZ_FILL_GROUP;
     if (n == 0) return 0;
     c.timer.begin("k_fill_hits", c.stream);
-    hipLaunchKernelGGL(k_fill_hits, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
-                       qcode, lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), cnt, off, base, keys);
+    hipLaunchKernelGGL(k_fill_hits, dim3((unsigned)((n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                       lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), cnt, pk, off, base, keys);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;

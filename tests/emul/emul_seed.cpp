@@ -93,7 +93,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     const u32 n = hi - lo;
     std::vector<u32> cnt(n); std::vector<u64> off(n + 1);
     u64 words = 0;
-    for (u32 i = 0; i < n; i++) { bool v; cnt[i] = lz_count_hits_at(qc, lo + i + 1, lo, E.sd, E.wstart.data(), v); words += v; }
+    for (u32 i = 0; i < n; i++) { bool v; u32 pkd; cnt[i] = lz_count_hits_at(qc, lo + i + 1, lo, E.sd, E.wstart.data(), v, pkd); words += v; }
     off[0] = 0; for (u32 i = 0; i < n; i++) off[i + 1] = off[i] + cnt[i];
     std::vector<LzChunk> chunks;
     rc = lzh_plan_chunks(n, E.hit_cap, 4096, [&](u32 i) { return off[i > n ? n : i]; }, chunks);
