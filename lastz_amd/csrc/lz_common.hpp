@@ -117,7 +117,74 @@ struct LzVec16 { u32 w[4]; };
 LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); return v; }
 #define LZ_VBYTE(v, k) (((v).w[(k) >> 2] >> (((k) & 3) * 8)) & 0xFFu)
 
-// One bucket (= one value of hashedDiag) of the diagonal hash: process its hits of this chunk
+// ---- phase A: every raw hit, independently (no diagEnd), scanned at most LZ_PROBE_CAP bases per
+// side.  The reference's two X-drop loops depend on the diagonal hash only through the left stop
+// position max(0, diagEnd[h]+diag) (:2612-2616); a scan that terminates on its own at query
+// position `lo` is therefore the scan the reference performs whenever diagEnd[h] <= lo.  The
+// summary lets the serial per-bucket pass (phase B) settle such hits without touching the
+// sequences; anything else (still alive at the cap, or scoring >= min_score so that an HSP
+// record is needed) is flagged SLOW and re-done in order by phase B.
+#define LZ_PROBE_CAP   128            // multiple of 16
+#define LZ_SUMM_SLOW   0x10000u
+#define LZ_SUMM_DLO(s)  ((s) & 0xFFu)         // pos2 - lo   (bases the left scan consumed)
+#define LZ_SUMM_DEXT(s) (((s) >> 8) & 0xFFu)  // extent - pos2 (bases the right scan consumed)
+
+LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, u64 key)
+{
+    const s32 xd = P.xdrop;
+    const u32 pos2 = (u32)key;
+    const s32 diag = (s32)(u32)(key >> 32);
+    const u32 pos1 = pos2 + (u32)diag;
+    const s32 stopl = diag > 0 ? diag : 0;                                               // diagEnd == 0
+    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
+    u32 sl = pos1, sr = pos1;
+    s32 runl = 0, bestl = 0, runr = 0, bestr = 0;
+    bool alive_l = ((s32)sl > stopl) && (0 >= -xd);
+    bool alive_r = ((s32)sr < stopr) && (0 >= -xd);
+    for (int blk = 0; blk < LZ_PROBE_CAP / 16 && (alive_l || alive_r); blk++) {
+        if (alive_l) {
+            const u32 room = (u32)((s32)sl - stopl);
+            const LzVec16 tv = lz_load16(P.tcode + sl - 16);
+            const LzVec16 qv = lz_load16(P.qcode + ((s32)sl - diag) - 16);
+            s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, 15 - k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, 15 - k))];
+            bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                if (go && (u32)k < room) { runl += sc[k]; --sl; if (runl > bestl) bestl = runl; go = runl >= bestl - xd; }
+            alive_l = go && ((s32)sl > stopl);
+        }
+        if (alive_r) {
+            const u32 room = (u32)(stopr - (s32)sr);
+            const LzVec16 tv = lz_load16(P.tcode + sr);
+            const LzVec16 qv = lz_load16(P.qcode + ((s32)sr - diag));
+            s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, k))];
+            bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int k = 0; k < 16; k++)
+                if (go && (u32)k < room) { runr += sc[k]; ++sr; if (runr > bestr) bestr = runr; go = runr >= bestr - xd; }
+            alive_r = go && ((s32)sr < stopr);
+        }
+    }
+    u32 summ = (pos1 - sl) | ((sr - pos1) << 8);
+    if (alive_l || alive_r || bestl + bestr >= P.min_score) summ |= LZ_SUMM_SLOW;
+    return summ;
+}
+
+// ---- phase B.  One bucket (= one value of hashedDiag) of the diagonal hash: process its hits of this chunk
 // in enumeration order.  This is process_for_simple_hit + xdrop_extend_seed_hit
 // (src/seed_search.c:1056-1192, 2528-2959) with diagEnd[h] held in a register.
 //   keys[i0..i1)  this bucket's hits, already in discovery order
@@ -133,7 +200,7 @@ LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); r
 // the X-drop test "run >= best - xDrop" gates each further base (:2623, :2684).
 template <class Emit>
 LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*32]*/,
-                           const u64* keys, u32 i0, u32 i1, u32 dend,
+                           const u64* keys, const u32* summ, u32 i0, u32 i1, u32 dend,
                            u64& n_ext, u64& n_bp, Emit&& emit)
 {
     const u32 L = P.seed_len;
@@ -147,12 +214,21 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
     for (;;) {
         if (!in_hit) {
             if (i >= i1) break;
-            const u64 key = keys[i++];
+            const u64 key = keys[i];
+            const u32 sm = summ[i];
+            i++;
             pos2 = (u32)key;
-            diag = (s32)(u32)(key >> 32);
-            pos1 = pos2 + (u32)diag;
             if (dend > pos2 - L) continue;                      // :1113
             n_ext++;
+            if (!(sm & LZ_SUMM_SLOW) && dend <= pos2 - LZ_SUMM_DLO(sm)) {
+                // phase A's scans are exactly the reference's for this diagEnd: settle the hit here
+                const u32 extent = pos2 + LZ_SUMM_DEXT(sm);     // :2785
+                if (extent > dend) dend = extent;
+                n_bp += LZ_SUMM_DLO(sm) + LZ_SUMM_DEXT(sm);     // :2818
+                continue;
+            }
+            diag = (s32)(u32)(key >> 32);
+            pos1 = pos2 + (u32)diag;
             stopl = (s32)dend + diag;  if (stopl < 0) stopl = 0;                               // :2612-2616
             stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
             sl = sr = left_start = right_stop = pos1;

@@ -63,6 +63,7 @@ struct LzCtx {
     // ---- seed-search scratch
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
     DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
+    DevBuf summ_a, summ_b;          // phase-A summaries, travelling with the keys
     DevBuf sort_tmp, scan_tmp;
     DevBuf bstart;                  // [LZ_DIAG_SIZE+1]
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
@@ -89,7 +90,8 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u64* valid_words_dev);
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys);
-int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u64 n);
+int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);
+int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n);
 int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart);
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* bstart, u32* diag_end,
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters);

@@ -1,0 +1,480 @@
+// lz_dp_dev.hpp -- the Y-drop gapped extension (ydrop_one_sided_align, src/gapped_extend.c:3388-3868)
+// as ONE WAVE PER ONE-SIDED DP, written once for the device and for the host test harness.
+//
+// Execution model.  lz_dp_run() is a sequence of PHASES.  A phase is a piece of per-lane code
+// (lane = 0..63) that only communicates with other lanes through the LzDpShared block; phases
+// are separated by barriers.  On the GPU, X::phase(f) runs f(lane) for the calling thread and
+// then __syncthreads() (one wave per workgroup, LzDpShared in LDS).  In tests/emul, X::phase(f)
+// runs f for lane 0..63 in turn.  Control flow between phases only depends on LzDpShared fields
+// written in an earlier phase, so it is wave-uniform by construction.
+//
+// Row algorithm.  The reference sweeps a row left to right with three
+// loop-carried values: the insertion score i, the running bestScore (for the Y-drop test) and the
+// left bound LY.  All three have closed parallel forms:
+//   * i is a max-plus prefix scan: i[c+1] = max(open[c], i[c]-gapE), open[c] = C_diag[c]-gapOE
+//     unless the cell is masked or its D beats the diagonal (no gap may open after a gap,
+//     :3714-3727).  Cells the reference prunes reset i to -inf; leaving such values in the scan is
+//     harmless because every value that differs is below the (non-decreasing) prune threshold.
+//   * the running bestScore before column c is max(best_at_row_start, max of diagonal-won cells
+//     left of c): a plain prefix max, because a cell that raises the best is never pruned.
+//   * LY advances over the leading pruned cells: LY' = first live column.
+// So a row is: walk 1 (per-lane block summaries of the i-recurrence) -> 64-lane scan -> walk 2
+// (cells, links, candidate bests) -> 64-lane prefix max -> walk 3 (prune test, stores,
+// traceback bytes) -> row end (right bound, overhang of insertions, :3786-3827).
+// Lane l owns cpl = ceil(width/64) consecutive columns of the row.
+#pragma once
+#include "lz_common.hpp"
+
+#define LZ_DP_LANES   64
+#define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
+#define LZ_DP_MAXACT  48              // active segments of earlier alignments crossing the sweep row
+#define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
+
+enum { LZ_DIAG_SEG = 0, LZ_HORZ_SEG = 1, LZ_VERT_SEG = 2 };
+enum { LZ_C_FROM_C = 0, LZ_C_FROM_I = 1, LZ_C_FROM_D = 2, LZ_I_EXT = 4, LZ_D_EXT = 8 };
+enum { LZ_DP_OK = 0, LZ_DP_TOO_WIDE = 1, LZ_DP_TB_SLOT = 2, LZ_DP_ROW_SLOT = 3, LZ_DP_OPS_SLOT = 4, LZ_DP_ACT_SLOT = 5 };
+
+struct LzDpSeg   { u32 b1, b2, e1, e2; s32 type; };
+struct LzDpAlign {                      // galign, src/gapped_extend.c:222-250 (indices instead of pointers, -1 = NULL)
+    u32 pos1, pos2, end1, end2;
+    s32 first_seg, last_seg;            // this alignment's segments are segs[first_seg..last_seg]
+    s32 left_align1, right_align1, left_align2, right_align2;
+    s32 left_seg1, right_seg1, left_seg2, right_seg2;
+};
+struct LzDpSnapshot {                   // the bounding alignments a batch of DPs is run against
+    const LzDpAlign* aligns; const LzDpSeg* segs;
+    const s32* obi; const s32* oed; s32 n_aligns;     // obi: by increasing start; oed: by decreasing end
+};
+
+struct LzDpJob {
+    u32 anchor1, anchor2; s32 reversed; u32 M, N;
+    s32 left_align, right_align, left_seg, right_seg;   // io->leftAlign.. (msp_left_right)
+    s32 list_start;                     // index into obi (forward: aboveList) / oed (reversed: belowList), -1 = none
+    u64 tb_off; u32 tb_cap;             // traceback bytes slot
+    u64 row_off; u32 row_cap;           // tbRow[] slot (u32 per row)
+    u64 ops_off; u32 ops_cap;           // edit ops slot (u32 each, traceback order)
+};
+
+struct LzDpResult {
+    s32 score; u32 end1, end2; u32 n_ops; u32 status; u32 truncated;
+    u32 max_row, min_col, max_col;      // explored region in DP coordinates (row 0..max_row)
+    u32 tb_used; u64 cells;
+};
+
+struct LzDpParams {                     // per batch
+    const u8* tdp; u32 tlen;            // DP-class codes of the target / query (unmasked scoring classes)
+    const u8* qdp; u32 qlen;
+    s32 gap_e, gap_oe, ydrop, ydrop_tail;
+    u32 tb_len;                         // the REFERENCE's traceback size (truncation rule, :3640-3661)
+    u8* tb_arena; u32* row_arena; u32* ops_arena;
+};
+
+struct LzDpActive { s32 align, seg; u32 x, last_row; s32 type; s32 filter; };
+
+struct LzDpShared {
+    s32 cc[LZ_DP_MAXW], dd[LZ_DP_MAXW];   // C[row][col], D[row+1][col]: ring, index col & (MAXW-1)
+    u32 mk[LZ_DP_MAXW];                   // mask stamps (= row number), :3706
+    u8  lk[LZ_DP_MAXW];                   // traceback link of the current row
+    // per-lane summaries
+    s32 sA[LZ_DP_LANES], sK[LZ_DP_LANES]; u32 sCut[LZ_DP_LANES];
+    s32 iIn[LZ_DP_LANES];
+    s32 cand[LZ_DP_LANES], runIn[LZ_DP_LANES]; u32 candCol[LZ_DP_LANES];
+    u32 firstLive[LZ_DP_LANES], lastLive[LZ_DP_LANES];
+    // sweep state (written by lane 0)
+    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter;
+    s32 best; u32 end1, end2;
+    s32 left_align, right_align, left_seg, right_seg, list_pos;
+    u32 tb_used, n_act, done, status, truncated, n_prolong;
+    s32 i_last;
+    u32 max_row, min_col, max_col; u64 cells;
+    LzDpActive act[LZ_DP_MAXACT];
+};
+
+struct LzDpLane { s32 c_left_old; };    // per-lane value carried between phases of one row
+
+// ---- sequence access: A is the vertical (target) string, B the horizontal (query) string, both
+// 1-based in DP coordinates (src/gapped_extend.c:2512-2533)
+LZ_HD u32 lz_dp_a(const LzDpParams& P, const LzDpJob& J, u32 row)
+{ return J.reversed ? P.tdp[(s64)J.anchor1 + 1 - (s64)row] : P.tdp[(s64)J.anchor1 + (s64)row]; }
+LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
+{ return J.reversed ? P.qdp[(s64)J.anchor2 + 1 - (s64)col] : P.qdp[(s64)J.anchor2 + (s64)col]; }
+
+#define LZ_SDIFF(a, b) (((s32)(a)) - ((s32)(b)))
+#define LZ_RING(c) ((c) & (LZ_DP_MAXW - 1))
+
+// next_sweep_seg / prev_sweep_seg, src/gapped_extend.c:4754-4850
+LZ_HD s32 lz_dp_next_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, s32& al, u32 row, u32 a1, u32 a2)
+{
+    seg = (seg < S.aligns[al].last_seg) ? seg + 1 : -1;
+    if (seg >= 0) {
+        if (S.segs[seg].type == LZ_HORZ_SEG) seg = (seg < S.aligns[al].last_seg) ? seg + 1 : -1;   // (the reference aborts on a trailing horizontal)
+        if (seg >= 0) return LZ_SDIFF(S.segs[seg].b2, a2);
+        return 0;
+    }
+    if (look_right) { seg = S.aligns[al].right_seg2; al = S.aligns[al].right_align2; }
+    else            { seg = S.aligns[al].left_seg2;  al = S.aligns[al].left_align2; }
+    if (seg < 0) return 0;
+    if (S.segs[seg].type == LZ_DIAG_SEG) return (s32)row + LZ_SDIFF(S.segs[seg].b2, a2) - LZ_SDIFF(S.segs[seg].b1, a1);
+    return LZ_SDIFF(S.segs[seg].b2, a2);
+}
+LZ_HD s32 lz_dp_prev_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, s32& al, u32 row, u32 a1, u32 a2)
+{
+    seg = (seg > S.aligns[al].first_seg) ? seg - 1 : -1;
+    if (seg >= 0) {
+        if (S.segs[seg].type == LZ_HORZ_SEG) seg = (seg > S.aligns[al].first_seg) ? seg - 1 : -1;
+        if (seg >= 0) return LZ_SDIFF(a2, S.segs[seg].e2);
+        return 0;
+    }
+    if (look_right) { seg = S.aligns[al].right_seg1; al = S.aligns[al].right_align1; }
+    else            { seg = S.aligns[al].left_seg1;  al = S.aligns[al].left_align1; }
+    if (seg < 0) return 0;
+    if (S.segs[seg].type == LZ_DIAG_SEG) return (s32)row + LZ_SDIFF(a2, S.segs[seg].e2) - LZ_SDIFF(a1, S.segs[seg].e1);
+    return LZ_SDIFF(a2, S.segs[seg].e2);
+}
+
+LZ_HD u32 lz_dp_special_min(u32 ry, s32 r) { if (r <= 0) return 0; if ((u32)r < ry) return (u32)r; return ry; }
+
+// update_LR_bounds, src/gapped_extend.c:4588-4700 (lane 0)
+LZ_HD void lz_dp_update_lr(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+{
+    s32 L = sh.L, R = sh.R; u32 LY = sh.LY, RY = sh.RY;
+    const u32 row = sh.row, a1 = J.anchor1, a2 = J.anchor2;
+    if (!J.reversed) {
+        if (sh.left_seg >= 0) {
+            if (S.segs[sh.left_seg].e1 >= row + a1) { if (S.segs[sh.left_seg].type == LZ_DIAG_SEG) L++; }
+            else L = lz_dp_next_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) + 1;
+        }
+        if (sh.left_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
+        if (sh.right_seg >= 0) {
+            if (S.segs[sh.right_seg].e1 >= row + a1) { if (S.segs[sh.right_seg].type == LZ_DIAG_SEG) R++; }
+            else R = lz_dp_next_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) - 1;
+        }
+        if (sh.right_seg >= 0) RY = lz_dp_special_min(RY, R);
+    } else {
+        if (sh.right_seg >= 0) {
+            if (S.segs[sh.right_seg].b1 <= a1 - row) { if (S.segs[sh.right_seg].type == LZ_DIAG_SEG) L++; }
+            else L = lz_dp_prev_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) + 1;
+        }
+        if (sh.right_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
+        if (sh.left_seg >= 0) {
+            if (S.segs[sh.left_seg].b1 <= a1 - row) { if (S.segs[sh.left_seg].type == LZ_DIAG_SEG) R++; }
+            else R = lz_dp_prev_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) - 1;
+        }
+        if (sh.left_seg >= 0) RY = lz_dp_special_min(RY, R);
+    }
+    sh.L = L; sh.R = R; sh.LY = LY; sh.RY = RY;
+}
+
+// build_active_seg, src/gapped_extend.c:4992-5035.  The reference only stamps cells inside
+// [LY,RY]; stamps outside the band are never looked at, so here every column the ring can hold
+// (|x - LY| < MAXW) is stamped -- same visible behaviour.
+LZ_HD void lz_dp_stamp(LzDpShared& sh, u32 x, u32 row) { if (x + LZ_DP_MAXW > sh.LY && x < sh.LY + LZ_DP_MAXW) sh.mk[LZ_RING(x)] = row; }
+LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J, LzDpActive& act)
+{
+    const LzDpSeg& sg = S.segs[act.seg];
+    act.type = sg.type;
+    if (!J.reversed) { act.x = sg.b2 - J.anchor2; act.last_row = sg.e1 - J.anchor1; }
+    else             { act.x = J.anchor2 - sg.e2; act.last_row = J.anchor1 - sg.b1; }
+    if (act.type != LZ_HORZ_SEG) lz_dp_stamp(sh, act.x, sh.row);
+    else {
+        u32 horz_end = (!J.reversed) ? sg.e2 - J.anchor2 : J.anchor2 - sg.b2;
+        u32 i_min = sh.LY > act.x ? sh.LY : act.x;
+        u32 i_max = sh.RY < horz_end ? sh.RY : horz_end;
+        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = sh.row;
+    }
+}
+
+// update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
+LZ_HD void lz_dp_update_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+{
+    const u32 row = sh.row;
+    for (u32 k = 0; k < sh.n_act; k++) {
+        LzDpActive& act = sh.act[k];
+        if (act.last_row >= row) {
+            if (act.type == LZ_DIAG_SEG) act.x++;
+            lz_dp_stamp(sh, act.x, row);
+        } else {
+            const LzDpAlign& al = S.aligns[act.align];
+            s32 nx = J.reversed ? ((act.seg > al.first_seg) ? act.seg - 1 : -1) : ((act.seg < al.last_seg) ? act.seg + 1 : -1);
+            if (nx >= 0) {
+                act.seg = nx;
+                lz_dp_build_active(S, sh, J, act);
+                if (act.type == LZ_HORZ_SEG) {
+                    act.seg = J.reversed ? act.seg - 1 : act.seg + 1;     // (a horizontal piece is never terminal)
+                    lz_dp_build_active(S, sh, J, act);
+                }
+            } else act.filter = 1;
+        }
+    }
+    // alignments the sweep row now reaches (the reference prepends; order within the list is immaterial)
+    if (sh.list_pos >= 0) {
+        const s32* order = J.reversed ? S.oed : S.obi;
+        while (sh.list_pos >= 0 && sh.list_pos < S.n_aligns) {
+            const LzDpAlign& al = S.aligns[order[sh.list_pos]];
+            bool hit = J.reversed ? (J.anchor1 - al.end1 == row) : (al.pos1 - J.anchor1 == row);
+            if (!hit) break;
+            if (sh.n_act >= LZ_DP_MAXACT) { sh.status = LZ_DP_ACT_SLOT; sh.done = 1; return; }
+            LzDpActive& act = sh.act[sh.n_act++];
+            act.filter = 0; act.align = order[sh.list_pos];
+            act.seg = J.reversed ? al.last_seg : al.first_seg;
+            lz_dp_build_active(S, sh, J, act);
+            sh.list_pos++;
+        }
+        if (sh.list_pos >= S.n_aligns) sh.list_pos = -1;
+    }
+    u32 w = 0;                                                 // filter_active_segs(&active, 0)
+    for (u32 k = 0; k < sh.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
+    sh.n_act = w;
+}
+
+LZ_HD void lz_dp_ops_add(u32* ops, u32& n, u32 cap, u32& status, u32 op)
+{   // edit_script_add(script, op, 1), src/edit_script.c:261-300 (repeat counts never reach 2^30 here)
+    if (n > 0 && (ops[n - 1] & 3u) == op) { ops[n - 1] += 4u; return; }
+    if (n >= cap) { status = LZ_DP_OPS_SLOT; return; }
+    ops[n++] = op | 4u;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class X>
+LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
+                     const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
+{
+    const s32 gapE = P.gap_e, gapOE = P.gap_oe, Y = P.ydrop;
+    const u32 M = J.M, N = J.N;
+    u8*  tb   = P.tb_arena  + J.tb_off;
+    u32* trow = P.row_arena + J.row_off;
+    u32* ops  = P.ops_arena + J.ops_off;
+
+    if (N == 0 || M == 0) {                                     // :3466-3467
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; } });
+        return;
+    }
+
+    // ---- set-up + row 0 (:3500-3605)
+    x.phase([&](int lane, LzDpLane&) {
+        if (lane != 0) return;
+        s32 L = 0, R = (s32)N + 1;
+        if (J.left_seg >= 0)  { const LzDpSeg& g = S.segs[J.left_seg];  L = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) L -= LZ_SDIFF(g.b1, J.anchor1); }
+        if (J.right_seg >= 0) { const LzDpSeg& g = S.segs[J.right_seg]; R = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) R -= LZ_SDIFF(g.b1, J.anchor1); }
+        if (J.reversed) {                                       // note (14), :3536-3541
+            if (J.left_seg < 0 && J.right_seg >= 0)       { L = -R + 1; R = (s32)N + 1; }
+            else if (J.left_seg >= 0 && J.right_seg < 0)  { R = -L - 1; L = 0; }
+            else if (J.left_seg >= 0 && J.right_seg >= 0) { s32 t = -L - 1; L = -R + 1; R = t; }
+        }
+        sh.L = L; sh.R = R;
+        sh.left_align = J.left_align; sh.right_align = J.right_align; sh.left_seg = J.left_seg; sh.right_seg = J.right_seg;
+        sh.list_pos = J.list_start; sh.n_act = 0;
+        sh.done = 0; sh.status = LZ_DP_OK; sh.truncated = 0;
+        sh.best = 0; sh.end1 = sh.end2 = 0; sh.row = 0; sh.cells = 0;
+        sh.max_row = 0; sh.min_col = 0; sh.max_col = 0;
+        // row 0: C[0][0]=0, then insertions while the PREVIOUS column's C is >= -yDrop (note 13)
+        u32 n0 = 1; s32 prevc = 0, c = -gapOE;
+        while (n0 <= N && prevc >= -Y) { prevc = c; c -= gapE; n0++; }
+        if (n0 + 2 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
+        if (n0 > J.tb_cap || J.row_cap < 2) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; }
+        sh.LY = 0; sh.RY = n0; sh.tb_used = n0; sh.cells = n0;
+        if (!sh.done) trow[0] = 0;
+        sh.max_col = n0 ? n0 - 1 : 0;
+    });
+    if (!sh.done) {
+        x.phase([&](int lane, LzDpLane&) {
+            for (u32 col = (u32)lane; col < sh.RY; col += LZ_DP_LANES) {
+                s32 c = (col == 0) ? 0 : -gapOE - (s32)(col - 1) * gapE;
+                sh.cc[LZ_RING(col)] = c;
+                sh.dd[LZ_RING(col)] = c - gapOE;
+                tb[col] = (col == 0) ? 0 : LZ_C_FROM_I;
+            }
+        });
+    }
+
+    // ---- rows 1..M (:3607-3828)
+    while (!sh.done) {
+        // phase 0 (lane 0): bounds, active segments, traceback budget
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != 0) return;
+            if (sh.row >= M) { sh.done = 1; return; }
+            sh.row++;
+            sh.prevLY = sh.LY;
+            lz_dp_update_lr(S, sh, J);
+            lz_dp_update_active(S, sh, J);
+            if (sh.done) return;
+            if (sh.RY < sh.LY) sh.RY = sh.LY;                   // note 11
+            const u32 width = sh.RY - sh.LY;
+            const s32 tb_needed = (s32)width + P.ydrop_tail;
+            if ((s64)sh.tb_used + tb_needed >= (s64)P.tb_len) { sh.truncated = 1; sh.done = 1; sh.row--; return; }   // :3640-3661
+            if ((u64)sh.tb_used + (u64)tb_needed > (u64)J.tb_cap) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; return; }
+            if (width + (u32)P.ydrop_tail + 4 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
+            if (sh.row + 1 >= J.row_cap) { sh.status = LZ_DP_ROW_SLOT; sh.done = 1; return; }
+            trow[sh.row] = sh.tb_used - sh.LY;                  // tbRow[row], :3662 (u32 wrap intended)
+            sh.ry_iter = sh.RY;
+            sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
+        });
+        if (sh.done) break;
+        const u32 row = sh.row, LY0 = sh.LY, RYi = sh.ry_iter, cpl = sh.cpl;
+        const s32 best0 = sh.best;
+        const bool any_active = sh.n_act != 0;
+        const u32 arow = lz_dp_a(P, J, row) & 31u;
+        const s32* trow_tab = tab + (arow << 5);
+
+        // walk 1: block summaries of the insertion recurrence
+        x.phase([&](int lane, LzDpLane& r) {
+            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
+            r.c_left_old = (c0 < RYi && c0 > LY0) ? sh.cc[LZ_RING(c0 - 1)] : LZ_DP_NEGINF;
+            s32 c_left = r.c_left_old;
+            for (u32 col = c0; col < c1; col++) {
+                const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[lz_dp_b(P, J, col) & 31u];
+                const s32 d = sh.dd[LZ_RING(col)];
+                c_left = sh.cc[LZ_RING(col)];
+                const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
+                if (masked) { A = LZ_DP_NEGINF; K = 0; cut = 1; }
+                else {
+                    const s32 a2 = A - gapE;
+                    const s32 open = (d > cin) ? (LZ_DP_NEGINF - (1 << 24)) : cin - gapOE;
+                    A = open > a2 ? open : a2;
+                    K += gapE;
+                }
+            }
+            sh.sA[lane] = A; sh.sK[lane] = K; sh.sCut[lane] = cut;
+        });
+        // 64-lane exclusive scan of f_l(x) = cut ? A : max(A, x - K), x0 = -inf (:3679 "i = negInf")
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != 0) return;
+            s32 xv = LZ_DP_NEGINF;
+            for (int l = 0; l < LZ_DP_LANES; l++) {
+                sh.iIn[l] = xv;
+                const s32 t = xv - sh.sK[l];
+                xv = sh.sCut[l] ? sh.sA[l] : (sh.sA[l] > t ? sh.sA[l] : t);
+                if (xv < LZ_DP_NEGINF - (1 << 24)) xv = LZ_DP_NEGINF - (1 << 24);
+            }
+            sh.i_last = xv;
+        });
+        // walk 2: the cells (:3697-3767 without the prune test), candidate bests
+        x.phase([&](int lane, LzDpLane& r) {
+            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            s32 i = sh.iIn[lane], c_left = r.c_left_old;
+            s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
+            for (u32 col = c0; col < c1; col++) {
+                s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[lz_dp_b(P, J, col) & 31u];
+                s32 d = sh.dd[LZ_RING(col)];
+                c_left = sh.cc[LZ_RING(col)];
+                const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
+                u32 link;
+                if (masked) { link = 0x80; c = LZ_DP_NEGINF; d = LZ_DP_NEGINF; i = LZ_DP_NEGINF; }
+                else if (d > c || i > c) {
+                    if (d >= i) { c = d; link = LZ_C_FROM_D | LZ_I_EXT | LZ_D_EXT; }
+                    else        { c = i; link = LZ_C_FROM_I | LZ_I_EXT | LZ_D_EXT; }
+                    i -= gapE; d -= gapE;
+                } else {
+                    if (c >= cmax) { cmax = c; ccol = col; }     // candidate for bestScore (later column wins ties)
+                    const s32 c_open = c - gapOE;
+                    d -= gapE;
+                    if (c_open > d) { d = c_open; link = LZ_C_FROM_C; } else link = LZ_C_FROM_C | LZ_D_EXT;
+                    i -= gapE;
+                    if (c_open > i) i = c_open; else link |= LZ_I_EXT;
+                }
+                if (i < LZ_DP_NEGINF - (1 << 24)) i = LZ_DP_NEGINF - (1 << 24);
+                sh.cc[LZ_RING(col)] = c; sh.dd[LZ_RING(col)] = d; sh.lk[LZ_RING(col)] = (u8)link;
+            }
+            sh.cand[lane] = cmax; sh.candCol[lane] = ccol;
+        });
+        // 64-lane exclusive prefix max of the candidates, seeded with bestScore at row start
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != 0) return;
+            s32 rb = best0;
+            for (int l = 0; l < LZ_DP_LANES; l++) { sh.runIn[l] = rb; if (sh.cand[l] > rb) rb = sh.cand[l]; }
+        });
+        // walk 3: prune test against the running best, final stores, traceback bytes
+        x.phase([&](int lane, LzDpLane&) {
+            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            s32 rb = sh.runIn[lane];
+            u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
+            u8* tbr = tb + (u32)(trow[row] + c0);
+            for (u32 col = c0; col < c1; col++) {
+                const s32 c = sh.cc[LZ_RING(col)];
+                const u32 link = sh.lk[LZ_RING(col)];
+                bool live = (link != 0x80) && (c >= rb - Y);
+                if (live) {
+                    if (first == 0xFFFFFFFFu) first = col;
+                    last = col;
+                    if ((link & 3u) == LZ_C_FROM_C && c > rb) rb = c;
+                    *tbr = (u8)link;
+                } else {
+                    sh.cc[LZ_RING(col)] = LZ_DP_NEGINF; sh.dd[LZ_RING(col)] = LZ_DP_NEGINF;
+                    *tbr = 0;
+                }
+                tbr++;
+            }
+            sh.firstLive[lane] = first; sh.lastLive[lane] = last;
+        });
+        // row end (lane 0): new LY, best/end, right bound, overhang (:3769-3827)
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != 0) return;
+            u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu; s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
+            for (int l = 0; l < LZ_DP_LANES; l++) {
+                if (sh.firstLive[l] != 0xFFFFFFFFu) { if (first == 0xFFFFFFFFu) first = sh.firstLive[l]; last = sh.lastLive[l]; }
+                if (sh.cand[l] >= cmax) { cmax = sh.cand[l]; ccol = sh.candCol[l]; }
+            }
+            const u32 iter = RYi - LY0;
+            sh.cells += iter;
+            sh.tb_used += iter;
+            if (cmax >= best0) { sh.best = cmax; sh.end1 = row; sh.end2 = ccol; }       // :3731-3735
+            if (first == 0xFFFFFFFFu) { sh.LY = RYi; sh.done = 1; sh.n_prolong = 0; return; }   // LY >= RY: feasible region empty
+            sh.LY = first;
+            if (LY0 < sh.min_col) sh.min_col = LY0;
+            sh.max_row = row;
+            const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
+            u32 RY = RYi, np = 0;
+            s32 i = sh.i_last;
+            if (RY > last + 1) RY = last + 1;
+            else {
+                const s32 thr = sh.best - Y;
+                while (i >= thr && (s32)RY <= NN) { np++; RY++; i -= gapE; }            // counted here, stored in the next phase
+            }
+            sh.n_prolong = np;
+            sh.tb_used += np;
+            sh.RY = RY;                                             // (before the sentinel cell)
+            if (RY - 1 > sh.max_col) sh.max_col = RY - 1;
+        });
+        if (sh.done) break;
+        // overhang cells C=i, D=i-gapOE, link=I (:3799-3811) and the terminating -inf cell (:3818-3826)
+        x.phase([&](int lane, LzDpLane&) {
+            const u32 np = sh.n_prolong, RY = sh.RY, base = RY - np;
+            for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
+                const s32 iv = sh.i_last - (s32)k * gapE;
+                sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
+                tb[(u32)(trow[row] + base + k)] = LZ_C_FROM_I;
+            }
+            if (lane == 0) {
+                const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
+                if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; sh.RY = RY + 1; }
+            }
+        });
+    }
+
+    // ---- traceback (:3847-3859) and result (lane 0)
+    x.phase([&](int lane, LzDpLane&) {
+        if (lane != 0) return;
+        u32 n_ops = 0, status = sh.status;
+        if (status == LZ_DP_OK) {
+            u32 row = sh.end1, col = sh.end2; u32 prev_op = 0, op;
+            while (row >= 1 || col > 0) {
+                const u32 link = tb[(u32)(trow[row] + col)];
+                op = link & 3u;
+                if (prev_op == LZ_C_FROM_I && (link & LZ_I_EXT)) op = LZ_C_FROM_I;
+                if (prev_op == LZ_C_FROM_D && (link & LZ_D_EXT)) op = LZ_C_FROM_D;
+                if (op == LZ_C_FROM_I)      { col--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 1u); }
+                else if (op == LZ_C_FROM_D) { row--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 2u); }
+                else                        { row--; col--; lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 3u); }
+                if (status != LZ_DP_OK) break;
+                prev_op = op;
+            }
+        }
+        res->score = sh.best; res->end1 = sh.end1; res->end2 = sh.end2; res->n_ops = n_ops;
+        res->status = status; res->truncated = sh.truncated;
+        res->max_row = sh.max_row; res->min_col = sh.min_col; res->max_col = sh.max_col;
+        res->tb_used = sh.tb_used; res->cells = sh.cells;
+    });
+}

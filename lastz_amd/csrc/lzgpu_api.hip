@@ -118,7 +118,7 @@ extern "C" void lzgpu_shutdown(void)
     if (!c.inited) return;
     (void)hipStreamSynchronize(c.stream);
     c.timer.resolve();
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b,
                        &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
@@ -384,6 +384,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if (max_chunk) {
         if ((rc = c.keys_a.ensure((size_t)max_chunk * 8))) return rc;
         if (a->extend && (rc = c.keys_b.ensure((size_t)max_chunk * 8))) return rc;
+        if (a->extend && (rc = c.summ_a.ensure((size_t)max_chunk * 4))) return rc;
+        if (a->extend && (rc = c.summ_b.ensure((size_t)max_chunk * 4))) return rc;
     }
     const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
     if (a->extend && (rc = c.hsp_out.ensure((size_t)out_cap * sizeof(LzHspRec)))) return rc;
@@ -394,7 +396,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
 
     std::vector<lz_hsp> plain;
-    // ---- 3. per chunk: fill -> (stable bucket sort -> bounds -> bucket-serial extension)
+    // ---- 3. per chunk: fill -> (phase A probe -> stable bucket sort -> bounds -> phase B bucket-serial pass)
     for (auto& ch : chunks) {
         if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.pk.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
@@ -404,9 +406,10 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
             for (u64 k : hk) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); }
             continue;
         }
-        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), c.keys_b.as<u64>(), ch.nh))) return rc;
+        if ((rc = lzk_probe_hits(c, P, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.summ_a.as<u32>()))) return rc;
+        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), c.keys_b.as<u64>(), c.summ_a.as<u32>(), c.summ_b.as<u32>(), ch.nh))) return rc;
         if ((rc = lzk_bucket_bounds(c, c.keys_b.as<u64>(), ch.nh, c.bstart.as<u32>()))) return rc;
-        if ((rc = lzk_extend(c, P, c.keys_b.as<u64>(), c.bstart.as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+        if ((rc = lzk_extend(c, P, c.keys_b.as<u64>(), c.summ_b.as<u32>(), c.bstart.as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
                              c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters))) return rc;
     }
 

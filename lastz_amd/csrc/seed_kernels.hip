@@ -254,15 +254,40 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* p
     return 0;
 }
 
-// B2 step 3: stable partition by hashedDiag = key bits 32..47
-int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u64 n)
+// B2 step 3 (phase A): one thread per raw hit, any order -- capped X-drop scans, 4-byte summary
+__global__ void __launch_bounds__(LZ_TPB)
+k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* __restrict__ score_tab_g,
+             u32* __restrict__ summ)
+{
+    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
+    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_TPB) tab[k] = score_tab_g[k];
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
+    if (i < n) summ[i] = lz_probe_hit(P, tab, keys[i]);
+}
+
+int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ)
+{
+    if (n == 0) return 0;
+    c.timer.begin("k_probe_hits", c.stream);
+    hipLaunchKernelGGL(k_probe_hits, dim3((unsigned)((n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                       P, keys, n, score_tab, summ);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// B2 step 4: stable partition of (key, summary) by hashedDiag = key bits 32..47
+int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n)
 {
     size_t tmp = 0;
-    LZ_HIP(rocprim::radix_sort_keys(nullptr, tmp, keys_in, keys_out, (size_t)n, 32u, 32u + LZ_DIAG_BITS, c.stream));
+    LZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, summ_in, summ_out, (size_t)n,
+                                     32u, 32u + LZ_DIAG_BITS, c.stream));
     int rc = c.sort_tmp.ensure(tmp);
     if (rc) return rc;
     c.timer.begin("rocprim_sort_hits", c.stream);
-    LZ_HIP(rocprim::radix_sort_keys(c.sort_tmp.p, tmp, keys_in, keys_out, (size_t)n, 32u, 32u + LZ_DIAG_BITS, c.stream));
+    LZ_HIP(rocprim::radix_sort_pairs(c.sort_tmp.p, tmp, keys_in, keys_out, summ_in, summ_out, (size_t)n,
+                                     32u, 32u + LZ_DIAG_BITS, c.stream));
     c.timer.end(c.stream);
     return 0;
 }
@@ -287,10 +312,10 @@ int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart)
     return 0;
 }
 
-// B2 step 4: one lane per hash bucket
+// B2 step 5 (phase B): one lane per hash bucket
 #define LZ_EXT_TPB 64
 __global__ void __launch_bounds__(LZ_EXT_TPB)
-k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ bstart,
+k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ summ, const u32* __restrict__ bstart,
          u32* __restrict__ diag_end, const s32* __restrict__ score_tab_g,
          LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap, u64* __restrict__ counters)
 {
@@ -301,7 +326,7 @@ k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__
     const u32 i0 = bstart[h], i1 = bstart[h + 1];
     u64 n_ext = 0, n_bp = 0;
     if (i0 < i1) {
-        u32 d = lz_extend_bucket(P, tab, keys, i0, i1, diag_end[h], n_ext, n_bp,
+        u32 d = lz_extend_bucket(P, tab, keys, summ, i0, i1, diag_end[h], n_ext, n_bp,
             [&](const LzHspRec& r) {
                 u32 slot = atomicAdd(out_count, 1u);
                 if (slot < out_cap) out[slot] = r;
@@ -316,12 +341,12 @@ k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__
     }
 }
 
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* bstart, u32* diag_end,
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters)
 {
     c.timer.begin("k_extend", c.stream);
     hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, c.stream,
-                       P, keys, bstart, diag_end, score_tab, out, out_count, out_cap, counters);
+                       P, keys, summ, bstart, diag_end, score_tab, out, out_count, out_cap, counters);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;

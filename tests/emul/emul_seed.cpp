@@ -108,7 +108,12 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         for (u32 i = ch.i0; i < ch.i1; i++)
             if (cnt[i]) lz_fill_hits_at(qc, lo + i + 1, E.sd, E.wstart.data(), E.wpos.data(), keys.data() + (off[i] - ch.base));
         if (!a->extend) { for (u64 k : keys) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); } continue; }
-        std::stable_sort(keys.begin(), keys.end(), [](u64 x, u64 y) { return ((x >> 32) & 0xFFFF) < ((y >> 32) & 0xFFFF); });
+        // phase A on the unsorted hits, then the (key, summary) pairs are partitioned together
+        std::vector<std::pair<u64, u32>> kv(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, keys[i]) };
+        std::stable_sort(kv.begin(), kv.end(), [](auto& x, auto& y) { return ((x.first >> 32) & 0xFFFF) < ((y.first >> 32) & 0xFFFF); });
+        std::vector<u32> summ(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) { keys[i] = kv[i].first; summ[i] = kv[i].second; }
         u64 nk = keys.size();
         for (u64 i = 0; i <= nk; i++) {
             s32 bp = (i == 0) ? -1 : (s32)((keys[i - 1] >> 32) & 0xFFFF), b = (i == nk) ? (s32)LZ_DIAG_SIZE : (s32)((keys[i] >> 32) & 0xFFFF);
@@ -116,7 +121,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         }
         for (u32 h = 0; h < LZ_DIAG_SIZE; h++) {
             if (bstart[h] == bstart[h + 1]) continue;
-            diag_end[h] = lz_extend_bucket(P, tab, keys.data(), bstart[h], bstart[h + 1], diag_end[h], n_ext, n_bp,
+            diag_end[h] = lz_extend_bucket(P, tab, keys.data(), summ.data(), bstart[h], bstart[h + 1], diag_end[h], n_ext, n_bp,
                                            [&](const LzHspRec& r) { recs.push_back(r); });
         }
     }
