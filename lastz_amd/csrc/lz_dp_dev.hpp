@@ -27,7 +27,7 @@
 
 #define LZ_DP_LANES   64
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
-#define LZ_DP_MAXACT  48              // active segments of earlier alignments crossing the sweep row
+#define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
 enum { LZ_DIAG_SEG = 0, LZ_HORZ_SEG = 1, LZ_VERT_SEG = 2 };
@@ -81,7 +81,7 @@ struct LzDpShared {
     s32 cand[LZ_DP_LANES], runIn[LZ_DP_LANES]; u32 candCol[LZ_DP_LANES];
     u32 firstLive[LZ_DP_LANES], lastLive[LZ_DP_LANES];
     // sweep state (written by lane 0)
-    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter;
+    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter, ry_pro, sentinel;
     s32 best; u32 end1, end2;
     s32 left_align, right_align, left_seg, right_seg, list_pos;
     u32 tb_used, n_act, done, status, truncated, n_prolong;
@@ -435,22 +435,21 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             }
             sh.n_prolong = np;
             sh.tb_used += np;
-            sh.RY = RY;                                             // (before the sentinel cell)
+            sh.ry_pro = RY;                                         // right bound before the terminating cell
+            sh.sentinel = ((s32)RY <= NN) ? 1u : 0u;                // :3818-3826
+            sh.RY = RY + sh.sentinel;
             if (RY - 1 > sh.max_col) sh.max_col = RY - 1;
         });
         if (sh.done) break;
         // overhang cells C=i, D=i-gapOE, link=I (:3799-3811) and the terminating -inf cell (:3818-3826)
         x.phase([&](int lane, LzDpLane&) {
-            const u32 np = sh.n_prolong, RY = sh.RY, base = RY - np;
+            const u32 np = sh.n_prolong, RY = sh.ry_pro, base = RY - np;
             for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
                 const s32 iv = sh.i_last - (s32)k * gapE;
                 sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
                 tb[(u32)(trow[row] + base + k)] = LZ_C_FROM_I;
             }
-            if (lane == 0) {
-                const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
-                if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; sh.RY = RY + 1; }
-            }
+            if (lane == 0 && sh.sentinel) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; }
         });
     }
 

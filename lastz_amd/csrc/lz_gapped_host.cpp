@@ -1,0 +1,337 @@
+// lz_gapped_host.cpp -- see lz_gapped_host.hpp.  Pure host code (no HIP calls); the one-sided
+// DPs are delegated to an LzDpExecutor (the HIP executor in dp_kernels.hip).
+#include <string.h>
+#include <algorithm>
+#include "lz_gapped_host.hpp"
+
+#define SUBM(m, r, c) ((m)[((size_t)(r) << 8) | (size_t)(c)])
+enum { OP_INS = 1, OP_DEL = 2, OP_SUB = 3 };
+#define WORST_SCORE (-0x7FFFFFFF - 1)
+
+// ---- reduce_to_points / segment_peak, src/gapped_extend.c:463-559
+static u32 segment_peak(const u8* s1, const u8* s2, u32 len, const s32* sub)
+{
+    const u8 *t1 = s1, *t2 = s2;
+    if (len <= 31) return len / 2;
+    s32 sim = 0; u32 ix;
+    for (ix = 0; ix < 31; ix++) sim += SUBM(sub, *t1++, *t2++);
+    s32 best = sim; u32 peak = 31 / 2;
+    for (; ix < len; ix++) {
+        sim -= SUBM(sub, *s1++, *s2++);
+        sim += SUBM(sub, *t1++, *t2++);
+        if (sim > best) { best = sim; peak = ix - 31 / 2; }
+    }
+    return peak;
+}
+
+void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* segs, u32 n)
+{
+    for (u32 i = 0; i < n; i++) {
+        u32 peak = segment_peak(t + segs[i].pos1, q + segs[i].pos2, segs[i].length, sub);
+        segs[i].pos1 += peak; segs[i].pos2 += peak; segs[i].length = 0;
+    }
+}
+
+// qSegmentsByDecreasingScore, src/segment.c:1748-1771 (a total order up to identical records)
+static bool seg_before(const lz_segment& a, const lz_segment& b)
+{
+    if (a.s != b.s) return a.s > b.s;
+    if (a.length != b.length) return a.length < b.length;
+    if (a.pos2 != b.pos2) return a.pos2 < b.pos2;
+    if (a.pos1 != b.pos1) return a.pos1 < b.pos1;
+    return a.id < b.id;
+}
+
+struct Neighbours { s32 la, ls, ra, rs; };
+
+// msp_left_right, src/gapped_extend.c:3953-4028.  rc: 1 = ok, 0 = anchor lies on an alignment, -1 = internal
+static int msp_left_right(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbours& nb)
+{
+    u32 right = 0xFFFFFFFFu, left = 0xFFFFFFFFu;
+    nb.la = nb.ls = nb.ra = nb.rs = -1;
+    for (size_t o = 0; o < S.obi.size(); o++) {
+        const LzDpAlign& al = S.aligns[S.obi[o]];
+        if (al.pos1 > pos1) break;
+        if (al.end1 < pos1) continue;
+        s32 bp = -1;
+        for (s32 k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].e1 >= pos1) { bp = k; break; }
+        if (bp < 0) continue;
+        const LzDpSeg& g = S.segs[bp];
+        if (g.type == LZ_HORZ_SEG) return -1;
+        s32 x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+        if (x == 0) return 0;
+        if (x > 0 && (u32)x < right) { right = (u32)x; nb.ra = S.obi[o]; nb.rs = bp; }
+        else if (x < 0 && (u32)(-x) < left) { left = (u32)(-x); nb.la = S.obi[o]; nb.ls = bp; }
+    }
+    return 1;
+}
+
+// align_left_right, src/gapped_extend.c:4078-4180
+static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
+{
+    const u32 pos1 = m.pos1, pos2 = m.pos2, end1 = m.end1, end2 = m.end2;
+    u32 rob = 0xFFFFFFFFu, rot = 0xFFFFFFFFu, lob = 0xFFFFFFFFu, lot = 0xFFFFFFFFu;
+    s32 m_rob = -1, m_rot = -1, m_lob = -1, m_lot = -1, b_rob = -1, b_rot = -1, b_lob = -1, b_lot = -1;
+    for (size_t o = 0; o < S.obi.size(); o++) {
+        const s32 ai = S.obi[o];
+        const LzDpAlign& al = S.aligns[ai];
+        if (al.pos1 > end1 || al.end1 < pos1) continue;
+        s32 bp = -1, k; s32 x;
+        for (k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= pos1) { bp = k; break; }
+        if (bp >= 0 && S.segs[bp].b1 <= pos1) {
+            const LzDpSeg& g = S.segs[bp];
+            x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+            if (x > 0 && (u32)x < rob) { rob = (u32)x; m_rob = ai; b_rob = bp; }
+            else if (x < 0 && (u32)(-x) < lob) { lob = (u32)(-x); m_lob = ai; b_lob = bp; }
+        }
+        if (bp >= 0) {
+            s32 bq = -1;
+            for (k = bp; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= end1) { bq = k; break; }
+            if (bq >= 0) {
+                const LzDpSeg& g = S.segs[bq];
+                x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, end2) + LZ_SDIFF(end1, g.b1) : LZ_SDIFF(g.b2, end2);
+                if (x > 0 && (u32)x < rot) { rot = (u32)x; m_rot = ai; b_rot = bq; }
+                else if (x < 0 && (u32)(-x) < lot) { lot = (u32)(-x); m_lot = ai; b_lot = bq; }
+            }
+        }
+    }
+    m.right_align1 = m_rob; m.right_seg1 = b_rob; m.right_align2 = m_rot; m.right_seg2 = b_rot;
+    m.left_align1 = m_lob;  m.left_seg1 = b_lob;  m.left_align2 = m_lot;  m.left_seg2 = b_lot;
+}
+
+// insert_align, src/gapped_extend.c:4210-4245
+static void insert_align(LzHostSnapshot& S, s32 ai)
+{
+    const LzDpAlign& m = S.aligns[ai];
+    size_t p = 0;
+    while (p < S.obi.size() && S.aligns[S.obi[p]].pos1 < m.pos1) p++;
+    S.obi.insert(S.obi.begin() + p, ai);
+    p = 0;
+    while (p < S.oed.size() && S.aligns[S.oed[p]].end1 > m.end1) p++;
+    S.oed.insert(S.oed.begin() + p, ai);
+}
+
+// score_alignment, src/gapped_extend.c:5631-5675
+static s32 score_alignment(const LzGappedParams& G, u32 pos1, u32 pos2, const std::vector<u32>& sc)
+{
+    const u8 *s1 = G.t + pos1, *s2 = G.q + pos2;
+    s32 sim = 0;
+    for (u32 w : sc) {
+        u32 rpt = w >> 2, op = w & 3;
+        if (rpt == 0) continue;
+        if (op == OP_SUB) { const u8* stop = s1 + rpt; while (s1 < stop) sim += SUBM(G.sub, *(s1++), *(s2++)); }
+        else if (op == OP_INS) { sim -= G.gap_open + (s32)(rpt * (u32)G.gap_extend); s2 += rpt; }
+        else if (op == OP_DEL) { sim -= G.gap_open + (s32)(rpt * (u32)G.gap_extend); s1 += rpt; }
+    }
+    return sim;
+}
+
+struct Built {                          // ydrop_align's outputs (alignio)
+    s32 s; u32 start1, start2, stop1, stop2;
+    std::vector<u32> script;
+};
+
+// ydrop_align after the two one-sided DPs, src/gapped_extend.c:2520-2583
+static void splice_and_trim(const LzGappedParams& G, u32 a1, u32 a2, const LzDpResult& rl, const std::vector<u32>& ol,
+                            const LzDpResult& rr, const std::vector<u32>& orr, Built& b)
+{
+    b.start1 = a1 + 1 - rl.end1; b.start2 = a2 + 1 - rl.end2;
+    b.stop1 = a1 + rr.end1;      b.stop2 = a2 + rr.end2;
+    b.script = ol;                                           // left half: traceback order == forward order
+    if (!orr.empty()) {                                      // edit_script_reverse + edit_script_append
+        size_t k = orr.size();
+        u32 first = orr[k - 1];
+        if (!b.script.empty() && (b.script.back() & 3) == (first & 3)) { b.script.back() += (first >> 2) << 2; k--; }
+        while (k > 0) b.script.push_back(orr[--k]);
+    }
+    b.s = rr.score + rl.score;
+    std::vector<u32>& sc = b.script;
+    if (sc.empty()) return;
+    if ((sc[0] & 3) != OP_SUB) {                             // lop_initial_indels, :2589-2635
+        u32 p1 = b.start1, p2 = b.start2; size_t k;
+        for (k = 0; k < sc.size(); k++) {
+            u32 op = sc[k] & 3, rpt = sc[k] >> 2;
+            if (op == OP_SUB) break; else if (op == OP_INS) p2 += rpt; else if (op == OP_DEL) p1 += rpt;
+        }
+        if (k == sc.size()) b.s = WORST_SCORE;
+        else {
+            b.start1 = p1; b.start2 = p2;
+            sc.erase(sc.begin(), sc.begin() + k);
+            b.s = score_alignment(G, b.start1, b.start2, sc);
+        }
+    }
+    if ((sc.back() & 3) != OP_SUB) {                         // lop_final_indels, :2640-2683
+        u32 p1 = b.stop1, p2 = b.stop2; size_t k;
+        for (k = sc.size(); k > 0;) {
+            k--;
+            u32 op = sc[k] & 3, rpt = sc[k] >> 2;
+            if (op == OP_SUB) { k++; break; } else if (op == OP_INS) p2 -= rpt; else if (op == OP_DEL) p1 -= rpt;
+        }
+        if (k == 0) b.s = WORST_SCORE;
+        else {
+            b.stop1 = p1; b.stop2 = p2;
+            sc.resize(k);
+            b.s = score_alignment(G, b.start1, b.start2, sc);
+        }
+    }
+}
+
+// format_alignment + save_seg, src/gapped_extend.c:5153-5275: script -> diag / horz / vert pieces
+static void format_segments(const Built& b, std::vector<LzDpSeg>& segs)
+{
+    segs.clear();
+    const u32 beg1 = b.start1 + 1, end1 = b.stop1 + 1, beg2 = b.start2 + 1, end2 = b.stop2 + 1;
+    const u32 height = end1 - beg1 + 1, width = end2 - beg2 + 1;
+    u32 i = 0, j = 0; size_t k = 0;
+    while (i < height || j < width) {
+        u32 si = i, sj = j, run = 0;
+        while (k < b.script.size() && (b.script[k] & 3) == OP_SUB) { run += b.script[k] >> 2; k++; }
+        i += run; j += run;
+        LzDpSeg d; d.type = LZ_DIAG_SEG; d.b1 = beg1 + si - 1; d.b2 = beg2 + sj - 1; d.e1 = beg1 + i - 2; d.e2 = beg2 + j - 2;
+        if (!segs.empty()) {
+            const LzDpSeg& tail = segs.back();
+            LzDpSeg c; c.type = (d.b1 == tail.e1 + 1) ? LZ_HORZ_SEG : LZ_VERT_SEG;
+            c.b1 = tail.e1 + 1; c.b2 = tail.e2 + 1; c.e1 = d.b1 - 1; c.e2 = d.b2 - 1;
+            segs.push_back(c);
+        }
+        segs.push_back(d);
+        if (i < height || j < width) {
+            if (k < b.script.size()) {
+                u32 op = b.script[k] & 3, rpt = b.script[k] >> 2;
+                if (op == OP_INS) j += rpt; else if (op == OP_DEL) i += rpt;
+                k++;
+            }
+        }
+    }
+}
+
+// does alignment `al` have a cell inside the closed rectangle [r0,r1] x [c0,c1] (target x query)?
+static bool align_touches(const LzHostSnapshot& S, const LzDpAlign& al, s64 r0, s64 r1, s64 c0, s64 c1)
+{
+    if ((s64)al.pos1 > r1 || (s64)al.end1 < r0) return false;
+    for (s32 k = al.first_seg; k <= al.last_seg; k++) {
+        const LzDpSeg& g = S.segs[k];
+        if ((s64)g.b1 > r1 || (s64)g.e1 < r0 || (s64)g.b2 > c1 || (s64)g.e2 < c0) {
+            if (g.type != LZ_HORZ_SEG && g.type != LZ_VERT_SEG) continue;
+            if ((s64)g.b1 > r1 + 1 || (s64)g.e1 + 1 < r0 || (s64)g.b2 > c1 + 1 || (s64)g.e2 + 1 < c0) continue;
+        }
+        if (g.type == LZ_DIAG_SEG) {
+            s64 lo = std::max<s64>(std::max<s64>(r0 - (s64)g.b1, c0 - (s64)g.b2), 0);
+            s64 hi = std::min<s64>(std::min<s64>(r1 - (s64)g.b1, c1 - (s64)g.b2), (s64)g.e1 - (s64)g.b1);
+            if (lo <= hi) return true;
+        } else return true;                                    // gap pieces: bounding box overlap is enough
+    }
+    return false;
+}
+
+struct Spec {                           // one speculated anchor
+    u32 anchor_ix; u32 a1, a2; Neighbours nb;
+    size_t job_l, job_r;
+};
+
+int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,
+                      std::vector<lz_align>& out, std::vector<u32>& out_ops, LzGappedStats& st)
+{
+    out.clear(); out_ops.clear();
+    memset(&st, 0, sizeof(st));
+    if (G.tlen == G.qlen && memcmp(G.t, G.q, G.tlen) == 0) return LZGPU_NH_IDENTICAL;   // :1152-1189 not restated
+    if (G.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
+
+    std::sort(anchors, anchors + n_anchors, seg_before);       // batched_segments, :1675
+    st.anchors = n_anchors;
+
+    LzHostSnapshot S;
+    struct Info { s32 s; u32 beg1, beg2, end1, end2; std::vector<u32> script; };
+    std::vector<Info> info;                                    // parallel to S.aligns
+
+    const u32 W = G.window ? G.window : 1024;
+    u32 next = 0;
+    std::vector<LzDpJob> jobs; std::vector<LzDpResult> res; std::vector<std::vector<u32>> ops;
+    std::vector<Spec> win;
+    while (next < n_anchors) {
+        // ---- speculation window against the current snapshot
+        win.clear(); jobs.clear();
+        u32 j = next;
+        for (; j < n_anchors && win.size() < W; j++) {
+            Spec sp; sp.anchor_ix = j; sp.a1 = anchors[j].pos1; sp.a2 = anchors[j].pos2;
+            int ok = msp_left_right(S, sp.a1, sp.a2, sp.nb);
+            if (ok < 0) return LZGPU_ERR_STATE;
+            if (ok == 0) continue;                             // on an earlier alignment: gone for good
+            // get_above_below, :4043-4059
+            s32 below = -1, above = -1;
+            for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < sp.a1) { below = (s32)o; break; }
+            for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > sp.a1) { above = (s32)o; break; }
+            LzDpJob L; memset(&L, 0, sizeof(L));
+            L.anchor1 = sp.a1; L.anchor2 = sp.a2; L.reversed = 1; L.M = sp.a1 + 1; L.N = sp.a2 + 1;
+            L.left_align = sp.nb.la; L.left_seg = sp.nb.ls; L.right_align = sp.nb.ra; L.right_seg = sp.nb.rs;
+            L.list_start = below;
+            LzDpJob R = L;
+            R.reversed = 0; R.M = G.tlen - (sp.a1 + 1); R.N = G.qlen - (sp.a2 + 1); R.list_start = above;
+            sp.job_l = jobs.size(); jobs.push_back(L);
+            sp.job_r = jobs.size(); jobs.push_back(R);
+            win.push_back(sp);
+        }
+        if (win.empty()) { next = j; break; }
+        const size_t n_snap = S.aligns.size();
+        res.assign(jobs.size(), LzDpResult());
+        ops.assign(jobs.size(), std::vector<u32>());
+        int rc = exec.run(S, jobs, res, ops);
+        if (rc) return rc;
+        st.rounds++; st.dp_runs += jobs.size();
+
+        // ---- commit in the reference's order
+        bool cut = false;
+        for (size_t w = 0; w < win.size(); w++) {
+            const Spec& sp = win[w];
+            const LzDpResult& rl = res[sp.job_l]; const LzDpResult& rr = res[sp.job_r];
+            if (S.aligns.size() > n_snap) {
+                Neighbours nb;
+                int ok = msp_left_right(S, sp.a1, sp.a2, nb);
+                if (ok < 0) return LZGPU_ERR_STATE;
+                if (ok == 0) continue;                         // now lies on an alignment committed in this window
+                bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
+                if (same) {
+                    // rectangles the two DPs explored, +-2 cells (target rows x query columns)
+                    s64 lr0 = (s64)sp.a1 + 1 - (s64)rl.max_row - 2, lr1 = (s64)sp.a1 + 2;
+                    s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
+                    s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
+                    s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
+                    for (size_t k = n_snap; k < S.aligns.size() && same; k++)
+                        if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1))
+                            same = false;
+                }
+                if (!same) { next = sp.anchor_ix; cut = true; st.reruns++; break; }
+            }
+            st.anchors_extended++;
+            st.dp_cells += rl.cells + rr.cells;
+            Built b;
+            splice_and_trim(G, sp.a1, sp.a2, rl, ops[sp.job_l], rr, ops[sp.job_r], b);
+            std::vector<LzDpSeg> segs;
+            format_segments(b, segs);
+            if (segs.empty()) continue;                        // empty alignment, :1401-1405
+            if (b.s < G.score_thresh) continue;                // :1419-1429 (allBounds == false)
+            LzDpAlign m; memset(&m, 0, sizeof(m));
+            m.pos1 = b.start1; m.pos2 = b.start2; m.end1 = b.stop1; m.end2 = b.stop2;
+            m.first_seg = (s32)S.segs.size(); m.last_seg = m.first_seg + (s32)segs.size() - 1;
+            align_left_right(S, m);
+            S.segs.insert(S.segs.end(), segs.begin(), segs.end());
+            S.aligns.push_back(m);
+            Info in; in.s = b.s; in.beg1 = b.start1 + 1; in.beg2 = b.start2 + 1; in.end1 = b.stop1 + 1; in.end2 = b.stop2 + 1;
+            in.script.swap(b.script);
+            info.push_back(std::move(in));
+            insert_align(S, (s32)S.aligns.size() - 1);
+        }
+        if (!cut) next = j;
+    }
+
+    // ---- output in increasing start order (orderBegInc), :1475-1566
+    for (s32 ai : S.obi) {
+        const Info& in = info[ai];
+        if (in.s < G.score_thresh) continue;
+        lz_align a; a.beg1 = in.beg1; a.beg2 = in.beg2; a.end1 = in.end1; a.end2 = in.end2; a.s = in.s;
+        a.script_len = (u32)in.script.size(); a.script_off = (u32)out_ops.size();
+        out_ops.insert(out_ops.end(), in.script.begin(), in.script.end());
+        out.push_back(a);
+    }
+    return 0;
+}

@@ -1,0 +1,44 @@
+// lz_gapped_host.hpp -- host orchestration of B3 (reduce_to_points + gapped_extend,
+// src/gapped_extend.c:463-559, 1012-1604), independent of how the one-sided DPs are executed.
+//
+// The reference extends anchors strictly one after another (best score first); every finished
+// alignment becomes a bound for the later ones and removes the anchors lying on it.  Here the DPs
+// of a WINDOW of upcoming anchors are run concurrently against a snapshot of the alignments
+// committed so far, and then committed in the reference's order.  A speculative DP is accepted
+// only if the reference would have run exactly the same DP: same neighbour segments at the
+// anchor (msp_left_right) and no alignment committed after the snapshot touching the region the
+// DP explored.  Otherwise the window is cut there and the anchor is re-run against the newer
+// snapshot.  See DESIGN.md section 4.3.
+#pragma once
+#include <vector>
+#include "lz_dp_dev.hpp"
+#include "../../include/lzgpu.h"
+
+struct LzHostSnapshot {
+    std::vector<LzDpAlign> aligns;
+    std::vector<LzDpSeg>   segs;
+    std::vector<s32>       obi, oed;
+};
+
+struct LzDpExecutor {
+    virtual ~LzDpExecutor() {}
+    // Runs jobs[k] (slot fields are the executor's business) against snap; res[k] and ops[k]
+    // (edit ops in traceback order) are filled.  Returns 0, LZGPU_NH_* or a negative error.
+    virtual int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs,
+                    std::vector<LzDpResult>& res, std::vector<std::vector<u32>>& ops) = 0;
+};
+
+struct LzGappedParams {
+    const u8* t; u32 tlen;                 // host copies of the sequences (anchor reduction, rescoring)
+    const u8* q; u32 qlen;
+    const s32* sub;                        // [256][256] unmasked scoring
+    s32 gap_open, gap_extend, ydrop, score_thresh;
+    u32 window;                            // max anchors speculated per round
+};
+
+struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns; };
+
+void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* segs, u32 n);
+
+int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,
+                      std::vector<lz_align>& out, std::vector<u32>& out_ops, LzGappedStats& st);

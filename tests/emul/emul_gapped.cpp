@@ -1,0 +1,89 @@
+// emul_gapped.cpp -- TEST INFRASTRUCTURE: executes the product's one-sided DP (lz_dp_dev.hpp, the
+// code the gfx950 kernel runs, one wave per DP) lane by lane, phase by phase on the CPU, under the
+// product's host orchestration (lz_gapped_host.cpp).  Lets "-m 'not gpu'" tests check the parallel
+// row algorithm and the speculative anchor windows against the oracle.  Never part of liblzgpu.so.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../lastz_amd/csrc/lz_gapped_host.hpp"
+#include "../../lastz_amd/csrc/lz_host.hpp"
+
+struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda for lanes 0..63
+    LzDpLane lanes[LZ_DP_LANES];
+    LzDpShared* dbg = nullptr; int np = 0;
+    template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); np++; if (dbg && getenv("EMUL_TRACE") && dbg->row < 26) fprintf(stderr, "ph %d row %u LY %u RY %u best %d ilast %d nprol %u L %d R %d\n", np, dbg->row, dbg->LY, dbg->RY, dbg->best, dbg->i_last, dbg->n_prolong, dbg->L, dbg->R); }
+};
+
+struct EmulExec : LzDpExecutor {
+    std::vector<u8> tdp, qdp;           // padded DP-class codes
+    u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
+    s32 gap_e, gap_oe, ydrop; u32 tb_len;
+    u32 tb_slot;                        // first-try slot size (tests shrink it to exercise the retry)
+    u64 retries = 0;
+    int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
+            std::vector<std::vector<u32>>& ops) override
+    {
+        LzDpSnapshot S; S.aligns = snap.aligns.data(); S.segs = snap.segs.data();
+        S.obi = snap.obi.data(); S.oed = snap.oed.data(); S.n_aligns = (s32)snap.aligns.size();
+        static LzDpShared sh;
+        for (size_t k = 0; k < jobs.size(); k++) {
+            u32 slot = tb_slot;
+            for (;;) {
+                std::vector<u8> tb(slot); std::vector<u32> rows(slot / 16 + 16), opbuf(slot / 4 + 16);
+                LzDpParams P; P.tdp = tdp.data() + LZ_SEQ_PAD; P.tlen = tlen; P.qdp = qdp.data() + LZ_SEQ_PAD; P.qlen = qlen;
+                P.gap_e = gap_e; P.gap_oe = gap_oe; P.ydrop = ydrop; P.ydrop_tail = ydrop / gap_e + 6; P.tb_len = tb_len;
+                P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data();
+                LzDpJob& J = jobs[k];
+                J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size();
+                CpuPhases x; x.dbg = &sh;
+                lz_dp_run(x, sh, S, P, J, tab, &res[k]);
+                if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
+                    if (slot >= tb_len) return LZGPU_ERR_STATE;
+                    slot = slot * 4 < tb_len ? slot * 4 : tb_len; retries++;
+                    continue;
+                }
+                if (res[k].status != LZ_DP_OK) { fprintf(stderr, "emul: job %zu status %u (row %u LY %u RY %u)\n", k, res[k].status, sh.row, sh.LY, sh.RY); return LZGPU_NH_UNSUPPORTED; }
+                ops[k].assign(opbuf.begin(), opbuf.begin() + res[k].n_ops);
+                break;
+            }
+        }
+        return 0;
+    }
+};
+
+static void dp_codes(const u8* seq, u32 len, const u8 cls[256], std::vector<u8>& out)
+{
+    out.assign((size_t)len + 2 * LZ_SEQ_PAD, 0);
+    for (u32 i = 0; i < len; i++) out[LZ_SEQ_PAD + i] = cls[seq[i]] & 31;
+}
+
+static LzGappedStats g_stats; static u64 g_retries;
+extern "C" void emul_gapped_stats(u64* out) { out[0] = g_stats.anchors; out[1] = g_stats.anchors_extended; out[2] = g_stats.dp_runs;
+    out[3] = g_stats.dp_cells; out[4] = g_stats.rounds; out[5] = g_stats.reruns; out[6] = g_retries; }
+
+extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, const s32* sub,
+                                  s32 gap_open, s32 gap_extend, s32 ydrop, s32 score_thresh, u32 tb_len,
+                                  lz_segment* anchors, u32 n_anchors, int reduce, u32 window, u32 tb_slot,
+                                  lz_align** out, u64* n_out, u32** ops, u64* n_ops)
+{
+    EmulExec ex;
+    u8 rowc[256], colc[256];
+    int rc = lzh_score_classes(sub, rowc, colc, ex.tab); if (rc) return rc;
+    dp_codes(t, tlen, rowc, ex.tdp); dp_codes(q, qlen, colc, ex.qdp);
+    ex.tlen = tlen; ex.qlen = qlen; ex.gap_e = gap_extend; ex.gap_oe = gap_open + gap_extend; ex.ydrop = ydrop;
+    ex.tb_len = tb_len ? tb_len : 80u * 1024 * 1024; ex.tb_slot = tb_slot ? tb_slot : (1u << 22);
+    LzGappedParams G; G.t = t; G.tlen = tlen; G.q = q; G.qlen = qlen; G.sub = sub;
+    G.gap_open = gap_open; G.gap_extend = gap_extend; G.ydrop = ydrop; G.score_thresh = score_thresh; G.window = window;
+    if (reduce) lzh_reduce_to_points(t, q, sub, anchors, n_anchors);
+    std::vector<lz_align> al; std::vector<u32> op;
+    rc = lzh_gapped_extend(G, ex, anchors, n_anchors, al, op, g_stats);
+    g_retries = ex.retries;
+    if (rc) return rc;
+    *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
+    *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);
+    if (!al.empty()) memcpy(*out, al.data(), al.size() * sizeof(lz_align));
+    if (!op.empty()) memcpy(*ops, op.data(), op.size() * 4);
+    *n_out = al.size(); *n_ops = op.size();
+    return 0;
+}
