@@ -205,6 +205,8 @@ int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* tot
 /* Tuning knobs (tests use small values to exercise the multi-chunk paths). */
 int lzgpu_set_hit_capacity(uint64_t max_hits_per_chunk);
 int lzgpu_set_hsp_capacity(uint64_t max_candidate_hsps);
+int lzgpu_set_dp_slot(uint32_t first_try_traceback_bytes_per_dp);
+int lzgpu_set_dp_window(uint32_t max_anchors_speculated_per_round);
 
 #ifdef __cplusplus
 }

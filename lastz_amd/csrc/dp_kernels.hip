@@ -1,0 +1,242 @@
+// dp_kernels.hip -- B3 on gfx950: the Y-drop one-sided DP kernel (one wave per DP, sweep row in
+// LDS, traceback bytes in HBM), the HIP executor that feeds it batches of speculative DPs, and the
+// lzgpu_gapped_extend entry point.  The algorithm itself is in lz_dp_dev.hpp (shared with the
+// CPU phase emulator used by the no-GPU tests); the anchor ordering / commit logic is in
+// lz_gapped_host.cpp.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include "lz_ctx.hpp"
+#include "lz_host.hpp"
+#include "lz_gapped_host.hpp"
+
+struct GpuPhases {                      // X for lz_dp_run: one thread = one lane, barrier after each phase
+    LzDpLane regs;
+    template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
+};
+
+__global__ void __launch_bounds__(LZ_DP_LANES)
+k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
+        const s32* __restrict__ tab_g, LzDpResult* __restrict__ res)
+{
+    __shared__ LzDpShared sh;
+    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
+    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
+    __syncthreads();
+    const u32 j = job_ids[blockIdx.x];
+    GpuPhases x;
+    lz_dp_run(x, sh, S, P, jobs[j], tab, &res[j]);
+}
+
+// gather the edit ops of a batch into one contiguous buffer (one block per job)
+__global__ void __launch_bounds__(256)
+k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ res, const u32* __restrict__ ops_arena,
+             const u64* __restrict__ dst_off, u32* __restrict__ dst)
+{
+    const u32 j = blockIdx.x;
+    const u32 n = res[j].n_ops;
+    const u32* src = ops_arena + jobs[j].ops_off;
+    u32* d = dst + dst_off[j];
+    for (u32 k = threadIdx.x; k < n; k += 256) d[k] = src[k];
+}
+
+struct DpBufs {
+    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out;
+};
+static DpBufs g_dp;
+
+struct HipDpExec : LzDpExecutor {
+    LzCtx& c;
+    LzDpParams P;                        // arenas filled per launch
+    u32 slot_tb;                         // first-try traceback slot (bytes) per DP
+    u64 dp_launch_cells = 0;
+    explicit HipDpExec(LzCtx& ctx) : c(ctx) {}
+
+    int launch(const LzDpSnapshot& S, std::vector<LzDpJob>& jobs, const std::vector<u32>& ids, u32 slot,
+               std::vector<LzDpResult>& res)
+    {
+        // slots: tb = slot bytes, rows = slot/16 entries, ops = slot/32 entries (all per DP)
+        const u64 n = ids.size();
+        const u32 row_cap = slot / 16 + 64, ops_cap = slot / 32 + 64;
+        int rc;
+        if ((rc = g_dp.tb.ensure((size_t)n * slot))) return rc;
+        if ((rc = g_dp.rows.ensure((size_t)n * row_cap * 4))) return rc;
+        if ((rc = g_dp.ops.ensure((size_t)n * ops_cap * 4))) return rc;
+        for (u64 k = 0; k < n; k++) {
+            LzDpJob& J = jobs[ids[k]];
+            J.tb_off = k * (u64)slot; J.tb_cap = slot;
+            J.row_off = k * (u64)row_cap; J.row_cap = row_cap;
+            J.ops_off = k * (u64)ops_cap; J.ops_cap = ops_cap;
+        }
+        if ((rc = g_dp.jobs.ensure(jobs.size() * sizeof(LzDpJob)))) return rc;
+        if ((rc = g_dp.ids.ensure(n * 4))) return rc;
+        if ((rc = g_dp.res.ensure(jobs.size() * sizeof(LzDpResult)))) return rc;
+        LZ_HIP(hipMemcpyAsync(g_dp.jobs.p, jobs.data(), jobs.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.stream));
+        P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
+        c.timer.begin("k_ydrop", c.stream);
+        hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+                           S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
+        c.timer.end(c.stream);
+        LZ_HIP(hipGetLastError());
+        // results of this launch
+        std::vector<LzDpResult> all(jobs.size());
+        LZ_HIP(hipMemcpyAsync(all.data(), g_dp.res.p, jobs.size() * sizeof(LzDpResult), hipMemcpyDeviceToHost, c.stream));
+        LZ_HIP(hipStreamSynchronize(c.stream));
+        c.timer.resolve();
+        for (u32 id : ids) res[id] = all[id];
+        return 0;
+    }
+
+    int fetch_ops(const std::vector<LzDpJob>& jobs, const std::vector<u32>& ids, const std::vector<LzDpResult>& res,
+                  std::vector<std::vector<u32>>& ops)
+    {
+        // one block per job of THIS launch (ids), ops compacted back to back
+        std::vector<u64> off(jobs.size(), 0); u64 total = 0;
+        std::vector<LzDpJob> sel; std::vector<LzDpResult> selr; std::vector<u64> seloff;
+        for (u32 id : ids) { sel.push_back(jobs[id]); selr.push_back(res[id]); seloff.push_back(total); total += res[id].n_ops; }
+        if (total == 0) return 0;
+        int rc;
+        DevBuf dj, dr;
+        if ((rc = dj.ensure(sel.size() * sizeof(LzDpJob)))) return rc;
+        if ((rc = dr.ensure(selr.size() * sizeof(LzDpResult)))) { dj.release(); return rc; }
+        if ((rc = g_dp.ops_off.ensure(seloff.size() * 8))) return rc;
+        if ((rc = g_dp.ops_out.ensure(total * 4))) return rc;
+        LZ_HIP(hipMemcpyAsync(dj.p, sel.data(), sel.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipMemcpyAsync(dr.p, selr.data(), selr.size() * sizeof(LzDpResult), hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.ops_off.p, seloff.data(), seloff.size() * 8, hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_gather_ops, dim3((unsigned)sel.size()), dim3(256), 0, c.stream,
+                           dj.as<LzDpJob>(), dr.as<LzDpResult>(), g_dp.ops.as<u32>(), g_dp.ops_off.as<u64>(), g_dp.ops_out.as<u32>());
+        LZ_HIP(hipGetLastError());
+        std::vector<u32> flat(total);
+        LZ_HIP(hipMemcpyAsync(flat.data(), g_dp.ops_out.p, total * 4, hipMemcpyDeviceToHost, c.stream));
+        LZ_HIP(hipStreamSynchronize(c.stream));
+        dj.release(); dr.release();
+        for (size_t k = 0; k < ids.size(); k++)
+            ops[ids[k]].assign(flat.begin() + seloff[k], flat.begin() + seloff[k] + res[ids[k]].n_ops);
+        return 0;
+    }
+
+    int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
+            std::vector<std::vector<u32>>& ops) override
+    {
+        int rc;
+        // ---- snapshot of the bounding alignments
+        const size_t na = snap.aligns.size(), ns = snap.segs.size();
+        if ((rc = g_dp.aligns.ensure((na ? na : 1) * sizeof(LzDpAlign)))) return rc;
+        if ((rc = g_dp.segs.ensure((ns ? ns : 1) * sizeof(LzDpSeg)))) return rc;
+        if ((rc = g_dp.obi.ensure((na ? na : 1) * 4))) return rc;
+        if ((rc = g_dp.oed.ensure((na ? na : 1) * 4))) return rc;
+        if (na) {
+            LZ_HIP(hipMemcpyAsync(g_dp.aligns.p, snap.aligns.data(), na * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.stream));
+            LZ_HIP(hipMemcpyAsync(g_dp.obi.p, snap.obi.data(), na * 4, hipMemcpyHostToDevice, c.stream));
+            LZ_HIP(hipMemcpyAsync(g_dp.oed.p, snap.oed.data(), na * 4, hipMemcpyHostToDevice, c.stream));
+        }
+        if (ns) LZ_HIP(hipMemcpyAsync(g_dp.segs.p, snap.segs.data(), ns * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.stream));
+        LzDpSnapshot S;
+        S.aligns = g_dp.aligns.as<LzDpAlign>(); S.segs = g_dp.segs.as<LzDpSeg>();
+        S.obi = g_dp.obi.as<s32>(); S.oed = g_dp.oed.as<s32>(); S.n_aligns = (s32)na;
+
+        // ---- first try: every job in a small slot; then the (rare) overflows in growing slots
+        std::vector<u32> ids(jobs.size());
+        for (u32 k = 0; k < jobs.size(); k++) ids[k] = k;
+        u32 slot = slot_tb;
+        while (!ids.empty()) {
+            // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch
+            const u64 per = (u64)slot + (u64)(slot / 16 + 64) * 4 + (u64)(slot / 32 + 64) * 4;
+            u64 max_jobs = (48ull << 30) / per; if (max_jobs < 1) max_jobs = 1;
+            std::vector<u32> retry;
+            for (size_t base = 0; base < ids.size(); base += max_jobs) {
+                std::vector<u32> part(ids.begin() + base, ids.begin() + std::min<size_t>(ids.size(), base + max_jobs));
+                if ((rc = launch(S, jobs, part, slot, res))) return rc;
+                std::vector<u32> good;
+                for (u32 id : part) {
+                    const u32 stt = res[id].status;
+                    if (stt == LZ_DP_OK) good.push_back(id);
+                    else if (stt == LZ_DP_TB_SLOT || stt == LZ_DP_ROW_SLOT || stt == LZ_DP_OPS_SLOT) retry.push_back(id);
+                    else return LZGPU_NH_UNSUPPORTED;              // band wider than the LDS ring / too many active segments
+                }
+                if ((rc = fetch_ops(jobs, good, res, ops))) return rc;
+            }
+            const u64 max_slot = std::max<u64>(P.tb_len, 1u << 20) * 2;
+            if (!retry.empty() && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
+            ids.swap(retry);
+            slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
+        }
+        return 0;
+    }
+};
+
+static u32 g_dp_slot_tb = 8u << 20;
+extern "C" int lzgpu_set_dp_slot(uint32_t bytes) { if (bytes < 65536) return LZGPU_ERR_ARG; g_dp_slot_tb = bytes; return 0; }
+static u32 g_dp_window = 1024;
+extern "C" int lzgpu_set_dp_window(uint32_t n) { if (n < 1) return LZGPU_ERR_ARG; g_dp_window = n; return 0; }
+
+int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len);     // lzgpu_api.hip
+int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256]);
+
+extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops)
+{
+    LzCtx& c = lz_ctx();
+    if (!a || !out || !n_out || !ops || !n_ops || !a->sub) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    *out = nullptr; *n_out = 0; *ops = nullptr; *n_ops = 0;
+    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    if (!c.have_table || c.target.host.empty()) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_prepare has not been called (the target is taken from it)");
+
+    // ---- query
+    SeqSlot* qs; int rc;
+    if (a->query) {
+        if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+        qs = &c.queries[-1];
+        if ((rc = lz_slot_upload_public(c, *qs, a->query, a->qlen))) return rc;
+    } else {
+        auto it = c.queries.find(a->query_slot);
+        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
+        qs = &it->second;
+    }
+    const u8* qhost = a->query ? a->query : qs->host.data();
+    const u32 qlen = qs->len, tlen = c.geom.tlen;
+
+    // ---- DP class codes (UNmasked scoring, src/lastz.c:3421)
+    u8 rowc[256], colc[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
+    if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
+    if ((rc = c.target.dp.ensure((size_t)tlen + 2 * LZ_SEQ_PAD + 16))) return rc;
+    if ((rc = qs->dp.ensure((size_t)qlen + 2 * LZ_SEQ_PAD + 16))) return rc;
+    LZ_HIP(hipMemsetAsync(c.target.dp.p, 0, (size_t)tlen + 2 * LZ_SEQ_PAD + 16, c.stream));
+    LZ_HIP(hipMemsetAsync(qs->dp.p, 0, (size_t)qlen + 2 * LZ_SEQ_PAD + 16, c.stream));
+    if ((rc = lz_encode_with(c, c.target.raw_base(), c.target.dp.as<u8>() + LZ_SEQ_PAD, tlen, rowc))) return rc;
+    if ((rc = lz_encode_with(c, qs->raw_base(), qs->dp.as<u8>() + LZ_SEQ_PAD, qlen, colc))) return rc;
+    if ((rc = g_dp.tab.ensure(sizeof(tab)))) return rc;
+    LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+
+    HipDpExec ex(c);
+    ex.P.tdp = c.target.dp.as<u8>() + LZ_SEQ_PAD; ex.P.tlen = tlen;
+    ex.P.qdp = qs->dp.as<u8>() + LZ_SEQ_PAD;      ex.P.qlen = qlen;
+    ex.P.gap_e = a->gap_extend; ex.P.gap_oe = a->gap_open + a->gap_extend; ex.P.ydrop = a->ydrop;
+    if (a->gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
+    ex.P.ydrop_tail = a->ydrop / a->gap_extend + 6;                      // :3484-3492
+    ex.P.tb_len = a->traceback_bytes ? a->traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
+    ex.slot_tb = g_dp_slot_tb;
+
+    LzGappedParams G;
+    G.t = c.target.host.data(); G.tlen = tlen; G.q = qhost; G.qlen = qlen; G.sub = a->sub;
+    G.gap_open = a->gap_open; G.gap_extend = a->gap_extend; G.ydrop = a->ydrop; G.score_thresh = a->score_thresh;
+    G.window = g_dp_window;
+    if (a->reduce) lzh_reduce_to_points(G.t, G.q, G.sub, a->anchors, a->n_anchors);
+    std::vector<lz_align> al; std::vector<u32> op; LzGappedStats st;
+    rc = lzh_gapped_extend(G, ex, a->anchors, a->n_anchors, al, op, st);
+    c.counters.anchors_extended += st.anchors_extended;
+    c.counters.dp_cells += st.dp_cells;                 // cells of the DPs the reference would have run
+    c.counters.gapped_extensions += st.dp_runs;         // DPs actually launched (speculation included)
+    if (rc) return rc < 0 ? lz_fail(rc, "gapped_extend failed") : rc;
+    *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
+    *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);
+    if (!*out || !*ops) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
+    if (!al.empty()) memcpy(*out, al.data(), al.size() * sizeof(lz_align));
+    if (!op.empty()) memcpy(*ops, op.data(), op.size() * 4);
+    *n_out = al.size(); *n_ops = op.size();
+    return 0;
+}

@@ -35,6 +35,7 @@ struct KernelTimer {
 struct SeqSlot {                    // a sequence resident in HBM
     DevBuf raw;                     // LZ_SEQ_PAD + len + LZ_SEQ_PAD bytes
     DevBuf code;                    // same geometry, code bytes (see lz_common.hpp)
+    DevBuf dp;                      // same geometry, DP score-class codes (unmasked scoring), B3 only
     u32    len = 0;
     bool   have_raw = false;
     uint64_t code_key = 0;          // hash of the (class map, charToBits) the codes were built with

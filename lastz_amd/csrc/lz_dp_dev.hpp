@@ -165,10 +165,9 @@ LZ_HD void lz_dp_update_lr(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob&
     sh.L = L; sh.R = R; sh.LY = LY; sh.RY = RY;
 }
 
-// build_active_seg, src/gapped_extend.c:4992-5035.  The reference only stamps cells inside
-// [LY,RY]; stamps outside the band are never looked at, so here every column the ring can hold
-// (|x - LY| < MAXW) is stamped -- same visible behaviour.
-LZ_HD void lz_dp_stamp(LzDpShared& sh, u32 x, u32 row) { if (x + LZ_DP_MAXW > sh.LY && x < sh.LY + LZ_DP_MAXW) sh.mk[LZ_RING(x)] = row; }
+// build_active_seg, src/gapped_extend.c:4992-5035: only cells inside [LY,RY] are stamped (that
+// also keeps the ring free of aliases: RY - LY < MAXW)
+LZ_HD void lz_dp_stamp(LzDpShared& sh, u32 x, u32 row) { if (x >= sh.LY && x <= sh.RY) sh.mk[LZ_RING(x)] = row; }
 LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J, LzDpActive& act)
 {
     const LzDpSeg& sg = S.segs[act.seg];
@@ -280,6 +279,8 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     });
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
+            // the mask stamps are row numbers: a previous job's stamps must not survive in the LDS block
+            for (u32 k = (u32)lane; k < LZ_DP_MAXW; k += LZ_DP_LANES) sh.mk[k] = 0;
             for (u32 col = (u32)lane; col < sh.RY; col += LZ_DP_LANES) {
                 s32 c = (col == 0) ? 0 : -gapOE - (s32)(col - 1) * gapE;
                 sh.cc[LZ_RING(col)] = c;

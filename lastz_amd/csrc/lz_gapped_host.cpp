@@ -245,18 +245,37 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::vector<Info> info;                                    // parallel to S.aligns
 
     const u32 W = G.window ? G.window : 1024;
+    // Which anchors of a window are worth a speculative DP.  Most anchors lie on the alignment an
+    // earlier (better) anchor is about to produce -- the reference drops them in msp_left_right
+    // without running a DP (98.5 % on the 10 Mbp pair).  An anchor within
+    // NEAR_DIAG diagonals and NEAR_POS target bases of an anchor already selected in this window
+    // is therefore deferred: when the commit pass reaches it, it is either on a committed
+    // alignment (skipped, as in the reference) or it starts the next window.  This only steers
+    // what is speculated; what is committed is decided by the checks below.
+    const s64 NEAR_DIAG = 1500, NEAR_POS = 60000;
     u32 next = 0;
     std::vector<LzDpJob> jobs; std::vector<LzDpResult> res; std::vector<std::vector<u32>> ops;
     std::vector<Spec> win;
+    struct Entry { u32 anchor_ix; s32 spec; };
+    std::vector<Entry> entries;
+    std::vector<std::pair<s64, s64>> chosen;                   // (diag, pos1) of selected anchors, this window
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        win.clear(); jobs.clear();
+        win.clear(); jobs.clear(); entries.clear(); chosen.clear();
         u32 j = next;
-        for (; j < n_anchors && win.size() < W; j++) {
+        const u32 scan_limit = 64 * W;
+        for (; j < n_anchors && win.size() < W && entries.size() < scan_limit; j++) {
             Spec sp; sp.anchor_ix = j; sp.a1 = anchors[j].pos1; sp.a2 = anchors[j].pos2;
             int ok = msp_left_right(S, sp.a1, sp.a2, sp.nb);
             if (ok < 0) return LZGPU_ERR_STATE;
             if (ok == 0) continue;                             // on an earlier alignment: gone for good
+            const s64 dg = (s64)sp.a1 - (s64)sp.a2;
+            bool defer = false;
+            for (auto& c : chosen)
+                if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
+                    c.second - (s64)sp.a1 <= NEAR_POS && (s64)sp.a1 - c.second <= NEAR_POS) { defer = true; break; }
+            if (defer) { entries.push_back({ j, -1 }); continue; }
+            chosen.push_back({ dg, (s64)sp.a1 });
             // get_above_below, :4043-4059
             s32 below = -1, above = -1;
             for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < sp.a1) { below = (s32)o; break; }
@@ -269,26 +288,33 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             R.reversed = 0; R.M = G.tlen - (sp.a1 + 1); R.N = G.qlen - (sp.a2 + 1); R.list_start = above;
             sp.job_l = jobs.size(); jobs.push_back(L);
             sp.job_r = jobs.size(); jobs.push_back(R);
+            entries.push_back({ j, (s32)win.size() });
             win.push_back(sp);
         }
-        if (win.empty()) { next = j; break; }
+        if (entries.empty()) { next = j; break; }
         const size_t n_snap = S.aligns.size();
         res.assign(jobs.size(), LzDpResult());
         ops.assign(jobs.size(), std::vector<u32>());
-        int rc = exec.run(S, jobs, res, ops);
-        if (rc) return rc;
+        if (!jobs.empty()) {
+            int rc = exec.run(S, jobs, res, ops);
+            if (rc) return rc;
+        }
         st.rounds++; st.dp_runs += jobs.size();
 
         // ---- commit in the reference's order
         bool cut = false;
-        for (size_t w = 0; w < win.size(); w++) {
-            const Spec& sp = win[w];
+        for (size_t e = 0; e < entries.size(); e++) {
+            const u32 aix = entries[e].anchor_ix;
+            Neighbours nb;
+            if (S.aligns.size() > n_snap || entries[e].spec < 0) {
+                int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
+                if (ok < 0) return LZGPU_ERR_STATE;
+                if (ok == 0) continue;                         // lies on an alignment committed meanwhile
+            }
+            if (entries[e].spec < 0) { next = aix; cut = true; break; }       // needs a DP: head of the next window
+            const Spec& sp = win[entries[e].spec];
             const LzDpResult& rl = res[sp.job_l]; const LzDpResult& rr = res[sp.job_r];
             if (S.aligns.size() > n_snap) {
-                Neighbours nb;
-                int ok = msp_left_right(S, sp.a1, sp.a2, nb);
-                if (ok < 0) return LZGPU_ERR_STATE;
-                if (ok == 0) continue;                         // now lies on an alignment committed in this window
                 bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
                 if (same) {
                     // rectangles the two DPs explored, +-2 cells (target rows x query columns)
@@ -300,7 +326,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                         if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1))
                             same = false;
                 }
-                if (!same) { next = sp.anchor_ix; cut = true; st.reruns++; break; }
+                if (!same) { next = aix; cut = true; st.reruns++; break; }
             }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;

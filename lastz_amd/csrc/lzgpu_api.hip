@@ -122,7 +122,8 @@ extern "C" void lzgpu_shutdown(void)
                        &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); }
+    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); }
+    c.target.dp.release();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
     c.stream = nullptr; c.inited = false; c.have_table = false; c.device = -1;
@@ -168,7 +169,18 @@ static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
     return 0;
 }
 
-static DevBuf g_cls_t, g_cls_q;
+static DevBuf g_cls_t, g_cls_q, g_cls_tmp;
+
+int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len) { return slot_upload(c, s, bytes, len, false); }
+int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256])
+{
+    int rc = g_cls_tmp.ensure(256); if (rc) return rc;
+    LZ_HIP(hipMemcpyAsync(g_cls_tmp.p, cls, 256, hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    if ((rc = lzk_encode(c, raw, code, len, g_cls_tmp.as<u8>()))) return rc;
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    return 0;
+}
 
 extern "C" int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen)
 {

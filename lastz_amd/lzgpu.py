@@ -58,7 +58,7 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdo
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_device_copy",
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
-           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity"]
+           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window"]
 
 
 class LzGpuError(RuntimeError):
@@ -246,6 +246,12 @@ class Lib:
 
     def set_hit_capacity(self, n):
         self._check(self._f("set_hit_capacity")(n), "set_hit_capacity")
+
+    def set_dp_slot(self, nbytes):
+        self._check(self.L.lzgpu_set_dp_slot(nbytes), "set_dp_slot")
+
+    def set_dp_window(self, n):
+        self._check(self.L.lzgpu_set_dp_window(n), "set_dp_window")
 
     def profile_enable(self, on=True):
         self.L.lzgpu_profile_enable(int(on))

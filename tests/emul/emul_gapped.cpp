@@ -11,8 +11,7 @@
 
 struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda for lanes 0..63
     LzDpLane lanes[LZ_DP_LANES];
-    LzDpShared* dbg = nullptr; int np = 0;
-    template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); np++; if (dbg && getenv("EMUL_TRACE") && dbg->row < 26) fprintf(stderr, "ph %d row %u LY %u RY %u best %d ilast %d nprol %u L %d R %d\n", np, dbg->row, dbg->LY, dbg->RY, dbg->best, dbg->i_last, dbg->n_prolong, dbg->L, dbg->R); }
+    template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
 };
 
 struct EmulExec : LzDpExecutor {
@@ -36,7 +35,7 @@ struct EmulExec : LzDpExecutor {
                 P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data();
                 LzDpJob& J = jobs[k];
                 J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size();
-                CpuPhases x; x.dbg = &sh;
+                CpuPhases x;
                 lz_dp_run(x, sh, S, P, J, tab, &res[k]);
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
                     if (slot >= tb_len) return LZGPU_ERR_STATE;

@@ -1,0 +1,96 @@
+"""CPU check of the B3 design: the product's one-sided DP (lz_dp_dev.hpp: the exact code the
+gfx950 kernel runs, one wave per DP, three parallel walks per row) executed lane by lane / phase
+by phase, under the product's host orchestration (speculative anchor windows, commit-in-order
+validation).  Must reproduce the oracle's alignments, edit scripts and DP-cell counts bit for bit."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from oracle import lzo
+from lastz_amd import seqio, lzgpu
+import helpers as H
+
+EMUL_DIR = os.path.join(H.ROOT, "tests", "emul")
+CS = os.path.join(H.ROOT, "lastz_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def L():
+    so = os.path.join(EMUL_DIR, "libemul.so")
+    srcs = [os.path.join(EMUL_DIR, "emul_seed.cpp"), os.path.join(EMUL_DIR, "emul_gapped.cpp"),
+            os.path.join(CS, "lz_host.cpp"), os.path.join(CS, "lz_gapped_host.cpp")]
+    deps = srcs + [os.path.join(CS, f) for f in ("lz_common.hpp", "lz_host.hpp", "lz_dp_dev.hpp", "lz_gapped_host.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+    lib = C.CDLL(so)
+    lib.emul_gapped_extend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
+                                       C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_uint64)]
+    return lib
+
+
+def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3000, tb_len=0):
+    t = np.ascontiguousarray(np.append(t, 0).astype(np.uint8)); q = np.ascontiguousarray(np.append(q, 0).astype(np.uint8))
+    segs = np.ascontiguousarray(segs.copy())
+    out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
+    rc = L.emul_gapped_extend(t.ctypes.data, len(t) - 1, q.ctypes.data, len(q) - 1, sub.ctypes.data, 400, 30, ydrop, thresh,
+                              tb_len, segs.ctypes.data, len(segs), 1, window, tb_slot,
+                              C.byref(out), C.byref(n), C.byref(ops), C.byref(nops))
+    assert rc == 0, rc
+    al = np.zeros(n.value, dtype=lzgpu.ALIGN_DTYPE); op = np.zeros(nops.value, dtype=np.uint32)
+    if n.value:
+        C.memmove(al.ctypes.data, out, n.value * al.itemsize)
+    if nops.value:
+        C.memmove(op.ctypes.data, ops, nops.value * 4)
+    st = (C.c_uint64 * 7)(); L.emul_gapped_stats(st)
+    return al, op, dict(zip(("anchors", "anchors_extended", "dp_runs", "dp_cells", "rounds", "reruns", "retries"), st))
+
+
+def _check(L, t, q, **kw):
+    sub, masked = H.scoring()
+    tab = lzo.Table(t, lzo.seed())
+    tot = {}
+    for _, rev, qq in H.strands(q):
+        hsps, _ = lzo.seed_hit_search(tab, qq, masked)
+        segs = lzo.hsps_to_segments(hsps, rev)
+        oal, oops, ost = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), ydrop=kw.get("ydrop", 9400),
+                                           tb_size=kw.get("tb_len", 0))
+        eal, eops, est = emul_gapped(L, t, qq, sub, segs.view(lzgpu.SEG_DTYPE), **kw)
+        assert len(oal) == len(eal) and (oal == eal).all() and (oops == eops).all()
+        assert est["dp_cells"] == ost["dp_cells"] and est["anchors_extended"] == ost["anchors_extended"]
+        for k, v in est.items():
+            tot[k] = tot.get(k, 0) + v
+    return tot
+
+
+def test_reference_inputs(L):
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+    for _, q in seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa")):
+        _check(L, tgt, q)
+    _, q = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))[0]
+    _check(L, tgt, q, window=1)                       # one anchor per round == the reference's serial loop
+    st = _check(L, tgt, q, tb_slot=65536)             # tiny first-try slots: overflow -> re-run in bigger ones
+    assert st["retries"] > 0
+
+
+@pytest.mark.parametrize("case", ["synth200k", "synth_overlap"])
+def test_golden_cases(L, case):
+    t, q = H.load_case(case)
+    _check(L, t, q)
+
+
+def test_obstacle_course(L):
+    """tandem repeats: hundreds of overlapping alignments bound / mask each other (L,R bounds, active
+    segments, window cuts and re-runs)"""
+    t, q = H.load_case("adversarial")
+    st = _check(L, t[9000:14500], q[29500:34000])
+    assert st["rounds"] > 3
+
+
+def test_traceback_truncation_rule(L):
+    """the reference truncates an alignment when its traceback arena runs out (:3640-3661)"""
+    t, q = H.load_case("synth_overlap")
+    _check(L, t, q, tb_len=1 << 20)

@@ -1,0 +1,109 @@
+"""Parity tests proper for B3 (reduce_to_points + gapped_extend): the HIP Y-drop DP kernel under
+the speculative anchor-window driver, called through the C ABI, against the reference's golden
+LAVs / the oracle.  Bit-exact: scores, block coordinates, every gap-free piece, block order, and
+the reference's 'DP cells visited' counter.  Needs an MI355X."""
+import os
+import numpy as np
+import pytest
+
+from oracle import lzo
+from lastz_amd import seqio, lzgpu
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+CTB = lzo.upper_nuc_to_bits()
+
+
+def _gpu_blocks(gpu, t, queries, **kw):
+    """whole hot path on the GPU: table -> HSPs -> gapped, per query and strand, as lastz drives it"""
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    out = []
+    gpu.counters_reset()
+    for ci, q in enumerate(queries):
+        for _, rev, qq in H.strands(q):
+            hsps = gpu.seed_hit_search(masked, q=qq)
+            segs = np.zeros(len(hsps), dtype=lzgpu.SEG_DTYPE)
+            segs["pos1"] = hsps["pos1"] - hsps["length"]; segs["pos2"] = hsps["pos2"] - hsps["length"]
+            segs["length"] = hsps["length"]; segs["s"] = hsps["score"]; segs["id"] = rev
+            al, ops = gpu.gapped_extend(sub, segs, q=qq, **kw)
+            if len(al):
+                out.append((ci + 1, rev, H.blocks_of(al, ops)))
+    return out, gpu.counters()
+
+
+def test_base_test_default_lav(gpu):
+    """make test: pseudocat x pseudopig, all defaults (src/Makefile:208-217) -- end to end on the GPU"""
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+    qs = [q for _, q in seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))]
+    mine, c = _gpu_blocks(gpu, tgt, qs)
+    assert mine == H.lav_blocks(os.path.join(H.GOLDEN, "base_test.default.lav"))
+    assert c["dp_cells"] == 21926949 and c["anchors_extended"] == 14
+
+
+@pytest.mark.parametrize("case", ["synth200k", "synth_overlap", "adversarial"])
+def test_golden_cases_against_reference_output(gpu, case):
+    t, q = H.load_case(case)
+    mine, c = _gpu_blocks(gpu, t, [q])
+    assert mine == H.lav_blocks(os.path.join(H.GOLDEN, case + ".lav"))
+    st = H.load_stats(case)
+    assert c["dp_cells"] == st["dp_cells"] and c["anchors_extended"] == st["anchors_extended"]
+
+
+def test_window_and_slot_invariance(gpu):
+    """results cannot depend on how many anchors are speculated per round or on the slot size"""
+    t, q = H.load_case("synth_overlap")
+    gold = H.lav_blocks(os.path.join(H.GOLDEN, "synth_overlap.lav"))
+    try:
+        for window, slot in ((1, 8 << 20), (3, 1 << 20), (4096, 65536)):
+            gpu.set_dp_window(window); gpu.set_dp_slot(slot)
+            mine, _ = _gpu_blocks(gpu, t, [q])
+            assert mine == gold
+    finally:
+        gpu.set_dp_window(1024); gpu.set_dp_slot(8 << 20)
+
+
+def test_thresholds_ydrop_truncation_vs_oracle(gpu):
+    t, q = H.load_case("synth_overlap")
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    tab = lzo.Table(t, lzo.seed())
+    for kw in (dict(ydrop=3000), dict(score_thresh=20000), dict(gap_open=200, gap_extend=60, ydrop=5000),
+               dict(traceback_bytes=1 << 20)):
+        for _, rev, qq in H.strands(q):
+            hsps, _ = lzo.seed_hit_search(tab, qq, masked)
+            segs = lzo.hsps_to_segments(hsps, rev)
+            okw = dict(kw); tb = okw.pop("traceback_bytes", 0)
+            oal, oops, _ = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), tb_size=tb, **okw)
+            al, ops = gpu.gapped_extend(sub, segs.view(lzgpu.SEG_DTYPE), q=qq, **kw)
+            assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
+
+
+def test_two_mbp_pair_vs_oracle(gpu):
+    t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=12)
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    for _, rev, qq in H.strands(q):
+        hsps = gpu.seed_hit_search(masked, q=qq)
+        segs = np.zeros(len(hsps), dtype=lzgpu.SEG_DTYPE)
+        segs["pos1"] = hsps["pos1"] - hsps["length"]; segs["pos2"] = hsps["pos2"] - hsps["length"]
+        segs["length"] = hsps["length"]; segs["s"] = hsps["score"]; segs["id"] = rev
+        gpu.counters_reset()
+        al, ops = gpu.gapped_extend(sub, segs, q=qq)
+        c = gpu.counters()
+        osegs = segs.view(lzo.SEG_DTYPE)
+        oal, oops, ost = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, osegs))
+        assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
+        assert c["dp_cells"] == ost["dp_cells"]
+        # every alignment re-scores to its score on the host (size-independent property)
+        for a in al[:50]:
+            s, p1, p2 = 0, int(a["beg1"]) - 1, int(a["beg2"]) - 1
+            for w in ops[int(a["script_off"]):int(a["script_off"] + a["script_len"])]:
+                op, n = int(w) & 3, int(w) >> 2
+                if op == 3:
+                    s += int(sub[t[p1:p1 + n], qq[p2:p2 + n]].sum()); p1 += n; p2 += n
+                elif op == 1:
+                    s -= 400 + 30 * n; p2 += n
+                else:
+                    s -= 400 + 30 * n; p1 += n
+            assert s == a["s"]
