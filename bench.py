@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--qlen", type=int, default=50_000_000)
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gapped", action="store_true",
+                    help="also time BASELINE.json configs[2]: the same pair with the gapped stage (--ydrop=9430)")
     a = ap.parse_args()
 
     import torch                                   # before liblzgpu.so: one HIP runtime per process
@@ -222,6 +224,46 @@ def main():
         dt = float(tt.item())
     lib.profile_enable(False)
 
+    gapped = None
+    if a.gapped:
+        # configs[2]: HSPs of each strand -> reduce_to_points -> gapped_extend (Y-drop DP), --ydrop=9430
+        hsps = [lib.seed_hit_search(masked, slot=slot) for slot in (0, 1)]
+        segs = []
+        for rev, h in enumerate(hsps):
+            sg = np.zeros(len(h), dtype=lzgpu.SEG_DTYPE)
+            sg["pos1"] = h["pos1"] - h["length"]; sg["pos2"] = h["pos2"] - h["length"]
+            sg["length"] = h["length"]; sg["s"] = h["score"]; sg["id"] = rev
+            segs.append(sg)
+        seed_prof, seed_cnt = lib.profile(), lib.counters()
+        lib.gapped_extend(sub, segs[0], slot=0, ydrop=9430)                      # warm-up (allocations)
+        lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
+        fence()
+        g0 = time.perf_counter()
+        nblocks = 0
+        for slot in (0, 1):
+            al, _ = lib.gapped_extend(sub, segs[slot], slot=slot, ydrop=9430)
+            nblocks += len(al)
+        fence()
+        gdt = time.perf_counter() - g0
+        gp, gc = lib.profile(), lib.counters()
+        lib.profile_enable(False)
+        kms = gp.get("k_ydrop", {"ms": 0.0, "launches": 0})
+        gapped = {"workload": "BASELINE.json configs[2]: same pair, gapped stage, --ydrop=9430, both strands",
+                  "wall_s": gdt, "anchors": int(len(segs[0]) + len(segs[1])), "alignments": nblocks,
+                  "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"],
+                  "dp_cells_reference": gc["dp_cells"], "gcups_wall": gc["dp_cells"] / gdt / 1e9,
+                  "k_ydrop_ms": kms["ms"], "k_ydrop_launches": kms["launches"],
+                  # algorithmic bytes of the DP, SURVEY 8(d): 1 traceback byte per visited cell
+                  "roofline": {"bound": "hbm", "kernel": "k_ydrop", "achieved": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9) if kms["ms"] else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms["ms"] else None,
+                               "traffic": None}}
+        # restore the seed-stage profile for the main line
+        class _P:  # noqa: E306
+            pass
+        lib.profile = lambda: seed_prof
+        lib.counters = lambda: seed_cnt
+
     if rank == 0:
         prof = lib.profile()
         cnt = lib.counters()
@@ -260,6 +302,8 @@ def main():
                "hsps_rank0": n_hsps[0],
                "counters_per_step": {"words": W, "raw_hits": Hh, "extensions": E, "bp_extended": X},
                "kernel_ms_per_step": kern_ms, "roofline": roof}
+        if gapped is not None:
+            out["gapped"] = gapped
         if world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline(target, q0, a.qlen, min(a.cpu_sample, a.tlen, a.qlen))
             out["cpu_baseline"] = cb
