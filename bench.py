@@ -227,6 +227,7 @@ def main():
     gapped = None
     if a.gapped:
         # configs[2]: HSPs of each strand -> reduce_to_points -> gapped_extend (Y-drop DP), --ydrop=9430
+        seed_prof, seed_cnt = lib.profile(), lib.counters()      # the main line's numbers, before this leg
         hsps = [lib.seed_hit_search(masked, slot=slot) for slot in (0, 1)]
         segs = []
         for rev, h in enumerate(hsps):
@@ -234,7 +235,6 @@ def main():
             sg["pos1"] = h["pos1"] - h["length"]; sg["pos2"] = h["pos2"] - h["length"]
             sg["length"] = h["length"]; sg["s"] = h["score"]; sg["id"] = rev
             segs.append(sg)
-        seed_prof, seed_cnt = lib.profile(), lib.counters()
         lib.gapped_extend(sub, segs[0], slot=0, ydrop=9430)                      # warm-up (allocations)
         lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
         fence()

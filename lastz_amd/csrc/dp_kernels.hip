@@ -15,6 +15,48 @@
 struct GpuPhases {                      // X for lz_dp_run: one thread = one lane, barrier after each phase
     LzDpLane regs;
     template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
+
+    // exclusive scan of the per-lane gap maps (Hillis-Steele over the wave's 64 lanes)
+    __device__ __forceinline__ s32 scan_gap(s32 x0)
+    {
+        const int lane = (int)threadIdx.x;
+        LzDpGap inc = { regs.A, regs.K, regs.cut };
+#pragma unroll
+        for (int d = 1; d < LZ_DP_LANES; d <<= 1) {
+            LzDpGap lo;
+            lo.A = __shfl_up(inc.A, d); lo.K = __shfl_up(inc.K, d); lo.cut = __shfl_up(inc.cut, d);
+            if (lane >= d) inc = lz_dp_gap_compose(lo, inc);
+        }
+        LzDpGap ex;
+        ex.A = __shfl_up(inc.A, 1); ex.K = __shfl_up(inc.K, 1); ex.cut = __shfl_up(inc.cut, 1);
+        regs.i_in = (lane == 0) ? x0 : lz_dp_gap_apply(ex, x0);
+        LzDpGap all;
+        all.A = __shfl(inc.A, LZ_DP_LANES - 1); all.K = __shfl(inc.K, LZ_DP_LANES - 1); all.cut = __shfl(inc.cut, LZ_DP_LANES - 1);
+        return lz_dp_gap_apply(all, x0);
+    }
+    __device__ __forceinline__ void scan_cand(s32 b0)
+    {
+        const int lane = (int)threadIdx.x;
+        s32 inc = regs.cand;
+#pragma unroll
+        for (int d = 1; d < LZ_DP_LANES; d <<= 1) { s32 v = __shfl_up(inc, d); if (lane >= d && v > inc) inc = v; }
+        s32 ex = __shfl_up(inc, 1);
+        regs.run_in = (lane == 0) ? b0 : (ex > b0 ? ex : b0);
+    }
+    __device__ __forceinline__ void reduce_row(LzDpShared& sh)
+    {
+        const int lane = (int)threadIdx.x;
+        const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
+        const s32 lo = has ? (s32)__ffsll((long long)has) - 1 : 0, hi = has ? 63 - (s32)__clzll((long long)has) : 0;
+        const u32 first = __shfl(regs.first, lo), last = __shfl(regs.last, hi);
+        s32 cmax = regs.cand;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { s32 v = __shfl_xor(cmax, d); if (v > cmax) cmax = v; }
+        const u64 att = __ballot(regs.cand == cmax);            // the LAST lane attaining the max owns the column
+        const u32 ccol = __shfl(regs.cand_col, 63 - (s32)__clzll((long long)att));
+        if (lane == 0) { sh.r_first = has ? first : 0xFFFFFFFFu; sh.r_last = has ? last : 0xFFFFFFFFu; sh.r_cmax = cmax; sh.r_ccol = ccol; }
+        __syncthreads();
+    }
 };
 
 __global__ void __launch_bounds__(LZ_DP_LANES)

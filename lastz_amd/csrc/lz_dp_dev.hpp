@@ -75,11 +75,8 @@ struct LzDpShared {
     s32 cc[LZ_DP_MAXW], dd[LZ_DP_MAXW];   // C[row][col], D[row+1][col]: ring, index col & (MAXW-1)
     u32 mk[LZ_DP_MAXW];                   // mask stamps (= row number), :3706
     u8  lk[LZ_DP_MAXW];                   // traceback link of the current row
-    // per-lane summaries
-    s32 sA[LZ_DP_LANES], sK[LZ_DP_LANES]; u32 sCut[LZ_DP_LANES];
-    s32 iIn[LZ_DP_LANES];
-    s32 cand[LZ_DP_LANES], runIn[LZ_DP_LANES]; u32 candCol[LZ_DP_LANES];
-    u32 firstLive[LZ_DP_LANES], lastLive[LZ_DP_LANES];
+    // row results of the cross-lane reduction (written by lane 0)
+    u32 r_first, r_last, r_ccol; s32 r_cmax;
     // sweep state (written by lane 0)
     s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter, ry_pro, sentinel;
     s32 best; u32 end1, end2;
@@ -90,7 +87,29 @@ struct LzDpShared {
     LzDpActive act[LZ_DP_MAXACT];
 };
 
-struct LzDpLane { s32 c_left_old; };    // per-lane value carried between phases of one row
+struct LzDpLane {                       // per-lane values carried between the steps of one row (registers on the GPU)
+    s32 c_left_old;
+    s32 A, K; u32 cut; s32 i_in;        // walk-1 summary f(x) = cut ? A : max(A, x-K), and the scanned input
+    s32 cand; u32 cand_col; s32 run_in; // best diagonal-won cell of the block; running best entering the block
+    u32 first, last;                    // first / last live column of the block (0xFFFFFFFF: none)
+};
+// Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
+// test harness); their semantics are fixed here:
+//   X::scan_gap(x0)   : r[l].i_in = (f_{l-1} o ... o f_0)(x0); returns (f_63 o ... o f_0)(x0)
+//                       composition g o f: A = g.cut ? g.A : max(g.A, f.A - g.K), K = f.K + g.K, cut = f.cut | g.cut
+//   X::scan_cand(b0)  : r[l].run_in = max(b0, cand_0 .. cand_{l-1})
+//   X::reduce_row(..) : first live column (lowest lane having one), last live column (highest lane),
+//                       max cand and the column of the LAST lane attaining it
+struct LzDpGap { s32 A, K; u32 cut; };
+LZ_HD LzDpGap lz_dp_gap_compose(const LzDpGap& f, const LzDpGap& g)      // g after f
+{
+    LzDpGap h;
+    const s32 t = f.A - g.K;
+    h.A = g.cut ? g.A : (g.A > t ? g.A : t);
+    h.K = f.K + g.K; h.cut = f.cut | g.cut;
+    return h;
+}
+LZ_HD s32 lz_dp_gap_apply(const LzDpGap& f, s32 x) { const s32 t = x - f.K; return f.cut ? f.A : (f.A > t ? f.A : t); }
 
 // ---- sequence access: A is the vertical (target) string, B the horizontal (query) string, both
 // 1-based in DP coordinates (src/gapped_extend.c:2512-2533)
@@ -338,24 +357,17 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                     K += gapE;
                 }
             }
-            sh.sA[lane] = A; sh.sK[lane] = K; sh.sCut[lane] = cut;
+            r.A = A; r.K = K; r.cut = cut;
         });
-        // 64-lane exclusive scan of f_l(x) = cut ? A : max(A, x - K), x0 = -inf (:3679 "i = negInf")
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane != 0) return;
-            s32 xv = LZ_DP_NEGINF;
-            for (int l = 0; l < LZ_DP_LANES; l++) {
-                sh.iIn[l] = xv;
-                const s32 t = xv - sh.sK[l];
-                xv = sh.sCut[l] ? sh.sA[l] : (sh.sA[l] > t ? sh.sA[l] : t);
-                if (xv < LZ_DP_NEGINF - (1 << 24)) xv = LZ_DP_NEGINF - (1 << 24);
-            }
-            sh.i_last = xv;
-        });
+        // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
+        {
+            const s32 i_end = x.scan_gap(LZ_DP_NEGINF);
+            x.phase([&](int lane, LzDpLane&) { if (lane == 0) sh.i_last = i_end; });
+        }
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.phase([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
-            s32 i = sh.iIn[lane], c_left = r.c_left_old;
+            s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
             for (u32 col = c0; col < c1; col++) {
                 s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[lz_dp_b(P, J, col) & 31u];
@@ -379,18 +391,14 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                 if (i < LZ_DP_NEGINF - (1 << 24)) i = LZ_DP_NEGINF - (1 << 24);
                 sh.cc[LZ_RING(col)] = c; sh.dd[LZ_RING(col)] = d; sh.lk[LZ_RING(col)] = (u8)link;
             }
-            sh.cand[lane] = cmax; sh.candCol[lane] = ccol;
+            r.cand = cmax; r.cand_col = ccol;
         });
         // 64-lane exclusive prefix max of the candidates, seeded with bestScore at row start
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane != 0) return;
-            s32 rb = best0;
-            for (int l = 0; l < LZ_DP_LANES; l++) { sh.runIn[l] = rb; if (sh.cand[l] > rb) rb = sh.cand[l]; }
-        });
+        x.scan_cand(best0);
         // walk 3: prune test against the running best, final stores, traceback bytes
-        x.phase([&](int lane, LzDpLane&) {
+        x.phase([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
-            s32 rb = sh.runIn[lane];
+            s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
             u8* tbr = tb + (u32)(trow[row] + c0);
             for (u32 col = c0; col < c1; col++) {
@@ -408,16 +416,13 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                 }
                 tbr++;
             }
-            sh.firstLive[lane] = first; sh.lastLive[lane] = last;
+            r.first = first; r.last = last;
         });
+        x.reduce_row(sh);
         // row end (lane 0): new LY, best/end, right bound, overhang (:3769-3827)
         x.phase([&](int lane, LzDpLane&) {
             if (lane != 0) return;
-            u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu; s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
-            for (int l = 0; l < LZ_DP_LANES; l++) {
-                if (sh.firstLive[l] != 0xFFFFFFFFu) { if (first == 0xFFFFFFFFu) first = sh.firstLive[l]; last = sh.lastLive[l]; }
-                if (sh.cand[l] >= cmax) { cmax = sh.cand[l]; ccol = sh.candCol[l]; }
-            }
+            const u32 first = sh.r_first, last = sh.r_last, ccol = sh.r_ccol; const s32 cmax = sh.r_cmax;
             const u32 iter = RYi - LY0;
             sh.cells += iter;
             sh.tb_used += iter;

@@ -2,6 +2,7 @@
 // DPs are delegated to an LzDpExecutor (the HIP executor in dp_kernels.hip).
 #include <string.h>
 #include <algorithm>
+#include <unordered_map>
 #include "lz_gapped_host.hpp"
 
 #define SUBM(m, r, c) ((m)[((size_t)(r) << 8) | (size_t)(c)])
@@ -224,11 +225,6 @@ static bool align_touches(const LzHostSnapshot& S, const LzDpAlign& al, s64 r0, 
     return false;
 }
 
-struct Spec {                           // one speculated anchor
-    u32 anchor_ix; u32 a1, a2; Neighbours nb;
-    size_t job_l, job_r;
-};
-
 int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,
                       std::vector<lz_align>& out, std::vector<u32>& out_ops, LzGappedStats& st)
 {
@@ -255,49 +251,64 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     const s64 NEAR_DIAG = 1500, NEAR_POS = 60000;
     u32 next = 0;
     std::vector<LzDpJob> jobs; std::vector<LzDpResult> res; std::vector<std::vector<u32>> ops;
-    std::vector<Spec> win;
-    struct Entry { u32 anchor_ix; s32 spec; };
+    struct Entry { u32 anchor_ix; bool speculated; };
+    // A finished speculative DP pair stays usable across windows for as long as its validity
+    // conditions hold against the alignments committed after the snapshot it ran against.
+    struct Cached { u32 a1, a2; Neighbours nb; size_t n_snap; LzDpResult rl, rr; std::vector<u32> ol, orr; };
+    std::unordered_map<u32, Cached> cache;
     std::vector<Entry> entries;
+    std::vector<u32> fresh;                                    // anchors launched in this round
     std::vector<std::pair<s64, s64>> chosen;                   // (diag, pos1) of selected anchors, this window
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        win.clear(); jobs.clear(); entries.clear(); chosen.clear();
+        jobs.clear(); entries.clear(); chosen.clear(); fresh.clear();
         u32 j = next;
         const u32 scan_limit = 64 * W;
-        for (; j < n_anchors && win.size() < W && entries.size() < scan_limit; j++) {
-            Spec sp; sp.anchor_ix = j; sp.a1 = anchors[j].pos1; sp.a2 = anchors[j].pos2;
-            int ok = msp_left_right(S, sp.a1, sp.a2, sp.nb);
+        const size_t n_snap = S.aligns.size();
+        for (; j < n_anchors && fresh.size() < W && entries.size() < scan_limit; j++) {
+            const u32 a1 = anchors[j].pos1, a2 = anchors[j].pos2;
+            Neighbours nb;
+            int ok = msp_left_right(S, a1, a2, nb);
             if (ok < 0) return LZGPU_ERR_STATE;
-            if (ok == 0) continue;                             // on an earlier alignment: gone for good
-            const s64 dg = (s64)sp.a1 - (s64)sp.a2;
-            bool defer = false;
-            for (auto& c : chosen)
-                if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
-                    c.second - (s64)sp.a1 <= NEAR_POS && (s64)sp.a1 - c.second <= NEAR_POS) { defer = true; break; }
-            if (defer) { entries.push_back({ j, -1 }); continue; }
-            chosen.push_back({ dg, (s64)sp.a1 });
+            if (ok == 0) { cache.erase(j); continue; }         // on an earlier alignment: gone for good
+            const s64 dg = (s64)a1 - (s64)a2;
+            auto hit = cache.find(j);
+            if (hit == cache.end()) {
+                bool defer = false;
+                for (auto& c : chosen)
+                    if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
+                        c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) { defer = true; break; }
+                if (defer) { entries.push_back({ j, false }); continue; }
+            }
+            chosen.push_back({ dg, (s64)a1 });
+            entries.push_back({ j, true });
+            if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
             s32 below = -1, above = -1;
-            for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < sp.a1) { below = (s32)o; break; }
-            for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > sp.a1) { above = (s32)o; break; }
+            for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < a1) { below = (s32)o; break; }
+            for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > a1) { above = (s32)o; break; }
             LzDpJob L; memset(&L, 0, sizeof(L));
-            L.anchor1 = sp.a1; L.anchor2 = sp.a2; L.reversed = 1; L.M = sp.a1 + 1; L.N = sp.a2 + 1;
-            L.left_align = sp.nb.la; L.left_seg = sp.nb.ls; L.right_align = sp.nb.ra; L.right_seg = sp.nb.rs;
+            L.anchor1 = a1; L.anchor2 = a2; L.reversed = 1; L.M = a1 + 1; L.N = a2 + 1;
+            L.left_align = nb.la; L.left_seg = nb.ls; L.right_align = nb.ra; L.right_seg = nb.rs;
             L.list_start = below;
             LzDpJob R = L;
-            R.reversed = 0; R.M = G.tlen - (sp.a1 + 1); R.N = G.qlen - (sp.a2 + 1); R.list_start = above;
-            sp.job_l = jobs.size(); jobs.push_back(L);
-            sp.job_r = jobs.size(); jobs.push_back(R);
-            entries.push_back({ j, (s32)win.size() });
-            win.push_back(sp);
+            R.reversed = 0; R.M = G.tlen - (a1 + 1); R.N = G.qlen - (a2 + 1); R.list_start = above;
+            jobs.push_back(L); jobs.push_back(R);
+            Cached cr; cr.a1 = a1; cr.a2 = a2; cr.nb = nb; cr.n_snap = n_snap;
+            cache.emplace(j, std::move(cr));
+            fresh.push_back(j);
         }
         if (entries.empty()) { next = j; break; }
-        const size_t n_snap = S.aligns.size();
-        res.assign(jobs.size(), LzDpResult());
-        ops.assign(jobs.size(), std::vector<u32>());
         if (!jobs.empty()) {
+            res.assign(jobs.size(), LzDpResult());
+            ops.assign(jobs.size(), std::vector<u32>());
             int rc = exec.run(S, jobs, res, ops);
             if (rc) return rc;
+            for (size_t k = 0; k < fresh.size(); k++) {
+                Cached& cr = cache[fresh[k]];
+                cr.rl = res[2 * k]; cr.rr = res[2 * k + 1];
+                cr.ol.swap(ops[2 * k]); cr.orr.swap(ops[2 * k + 1]);
+            }
         }
         st.rounds++; st.dp_runs += jobs.size();
 
@@ -306,32 +317,30 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         for (size_t e = 0; e < entries.size(); e++) {
             const u32 aix = entries[e].anchor_ix;
             Neighbours nb;
-            if (S.aligns.size() > n_snap || entries[e].spec < 0) {
-                int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
-                if (ok < 0) return LZGPU_ERR_STATE;
-                if (ok == 0) continue;                         // lies on an alignment committed meanwhile
+            int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
+            if (ok < 0) return LZGPU_ERR_STATE;
+            if (ok == 0) { cache.erase(aix); continue; }       // lies on an alignment committed meanwhile
+            if (!entries[e].speculated) { next = aix; cut = true; break; }    // needs a DP: head of the next window
+            auto it = cache.find(aix);
+            const Cached& sp = it->second;
+            const LzDpResult& rl = sp.rl; const LzDpResult& rr = sp.rr;
+            bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
+            if (same && S.aligns.size() > sp.n_snap) {
+                // rectangles the two DPs explored, +-2 cells (target rows x query columns)
+                s64 lr0 = (s64)sp.a1 + 1 - (s64)rl.max_row - 2, lr1 = (s64)sp.a1 + 2;
+                s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
+                s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
+                s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
+                for (size_t k = sp.n_snap; k < S.aligns.size() && same; k++)
+                    if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1))
+                        same = false;
             }
-            if (entries[e].spec < 0) { next = aix; cut = true; break; }       // needs a DP: head of the next window
-            const Spec& sp = win[entries[e].spec];
-            const LzDpResult& rl = res[sp.job_l]; const LzDpResult& rr = res[sp.job_r];
-            if (S.aligns.size() > n_snap) {
-                bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
-                if (same) {
-                    // rectangles the two DPs explored, +-2 cells (target rows x query columns)
-                    s64 lr0 = (s64)sp.a1 + 1 - (s64)rl.max_row - 2, lr1 = (s64)sp.a1 + 2;
-                    s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
-                    s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
-                    s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
-                    for (size_t k = n_snap; k < S.aligns.size() && same; k++)
-                        if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1))
-                            same = false;
-                }
-                if (!same) { next = aix; cut = true; st.reruns++; break; }
-            }
+            if (!same) { cache.erase(it); next = aix; cut = true; st.reruns++; break; }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
             Built b;
-            splice_and_trim(G, sp.a1, sp.a2, rl, ops[sp.job_l], rr, ops[sp.job_r], b);
+            splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, b);
+            cache.erase(it);
             std::vector<LzDpSeg> segs;
             format_segments(b, segs);
             if (segs.empty()) continue;                        // empty alignment, :1401-1405

@@ -59,7 +59,8 @@ extern "C" int emul_table_prepare(const u8* t, u32 tlen, u32 start, u32 end, con
     E.wstart.assign((size_t)nwords + 1, 0);
     for (u32 i = 0; i <= n; i++) {
         s64 kp = (i == 0) ? -1 : (s64)kv[i - 1].first, k = (i == n) ? (s64)nwords : (s64)kv[i].first;
-        if (k > nwords) k = nwords; if (kp > nwords) kp = nwords;
+        if (k > nwords) k = nwords;
+        if (kp > nwords) kp = nwords;
         for (s64 w = kp + 1; w <= k; w++) E.wstart[w] = i;
     }
     u32 nw = E.wstart[nwords];
