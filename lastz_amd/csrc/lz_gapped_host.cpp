@@ -324,17 +324,25 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             auto it = cache.find(aix);
             const Cached& sp = it->second;
             const LzDpResult& rl = sp.rl; const LzDpResult& rr = sp.rr;
+            // Is the cached DP the one the reference would run now?  Rectangles the two one-sided
+            // DPs explored, +-2 cells (target rows x query columns):
+            const s64 lr0 = (s64)sp.a1 + 1 - (s64)rl.max_row - 2, lr1 = (s64)sp.a1 + 2;
+            const s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
+            const s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
+            const s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
+            auto touched_from = [&](size_t k0) {
+                for (size_t k = k0; k < S.aligns.size(); k++)
+                    if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1)) return true;
+                return false;
+            };
+            // (a) same neighbour segments at the anchor as when it ran and nothing committed since
+            //     touches what it explored: identical inputs wherever the DP looked;
+            // (b) or no alignment at all touches what it explored: every bound (L, R, masks) the
+            //     reference would track lies outside the band on every row, whichever neighbours it
+            //     starts from, so the DP is the unconstrained one.
             bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
-            if (same && S.aligns.size() > sp.n_snap) {
-                // rectangles the two DPs explored, +-2 cells (target rows x query columns)
-                s64 lr0 = (s64)sp.a1 + 1 - (s64)rl.max_row - 2, lr1 = (s64)sp.a1 + 2;
-                s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
-                s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
-                s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
-                for (size_t k = sp.n_snap; k < S.aligns.size() && same; k++)
-                    if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1))
-                        same = false;
-            }
+            if (same) same = !touched_from(sp.n_snap);
+            else      same = !touched_from(0);
             if (!same) { cache.erase(it); next = aix; cut = true; st.reruns++; break; }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
