@@ -33,6 +33,22 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
+    (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, profiles/*pmc_fetch_write.csv).  Units and the
+    gfx950 correction follow MI355X_MICROARCH.md: counters are in KiB; FETCH_SIZE under-reports wide
+    reads by 2x (uncalibrated for 16-byte gathers: reported as measured x2 = upper bound)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")))
+    if not files:
+        return None, None
+    for line in open(files[-1]).read().split("\n")[1:]:
+        f = line.split(",")
+        if len(f) >= 4 and f[0] == kernel:
+            return (2.0 * float(f[2]) + float(f[3])) * 1024.0, os.path.basename(files[-1])
+    return None, None
+
+
 def cpu_baseline(t, q, qlen_bench, sample_bp):
     """The pristine reference (oracle/_ref/lastz_stats, built from /root/reference in the build
     container and shipped with the snapshot) on a bounded sample of the same workload, 1 core
@@ -170,12 +186,13 @@ def main():
     lib.query_upload(1, seqio.revcomp(query))
 
     def bcast_table():
+        from lastz_amd import shard
         for ptr, nbytes in lib.table_buffers():
             if nbytes == 0:
                 continue
             try:
                 tt = torch.as_tensor(_DevMem(ptr, nbytes), device=torch.device("cuda", local))
-                dist.broadcast(tt, src=0)
+                shard.broadcast_buffers(dist, [tt], src=0)            # RCCL over xGMI, zero copy
             except Exception:
                 stage = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", local))
                 if rank == 0:
@@ -281,8 +298,9 @@ def main():
             launches = prof[dom]["launches"] / K
             avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
             ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
                     "launches_per_step": launches,
                     "stage": {"b_seed_bytes_per_step": b_seed, "sum_kernel_ms_per_step": sum(kern_ms.values()),
