@@ -1,0 +1,245 @@
+/* lzgpu_shim.c -- the reference-side binding of liblzgpu.so.
+ *
+ * This is the one file a lastz maintainer adds.  It is written against the REFERENCE's own
+ * headers (the src/ .h files, found with -I at build time; nothing of the reference is copied here) and
+ * redefines the three hot-path entry points.  The reference's definitions of the same functions
+ * are kept, renamed ref_* by -D flags on the three files that define them (integration/Makefile),
+ * and serve every case outside the fast-path predicate -- never as a silent substitute for a
+ * failing GPU path: a negative return code from the library is fatal (suicidef), exactly like
+ * every other error in the reference (src/utilities.c:1866-1884).
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdbool.h>
+#include "build_options.h"
+#include "utilities.h"
+#include "dna_utilities.h"
+#include "sequences.h"
+#include "seeds.h"
+#include "pos_table.h"
+#include "segment.h"
+#include "edit_script.h"
+#include "seed_search.h"
+#include "gapped_extend.h"
+#include "diag_hash.h"
+#include "lzgpu.h"
+
+/* the reference's own routines, renamed at compile time */
+postable* ref_build_seed_position_table (seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* seed, u32 step);
+void      ref_free_position_table (postable* pt);
+void      ref_mask_seed_position_table (postable* pt, seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed);
+void      ref_limit_position_table (postable* pt, u32 limit, unspos maxChasm);
+u64       ref_seed_hit_search (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end, int selfCompare,
+                               const s8 upperCharToBits[], seed* hitSeed, u32 searchLimit, u32 reportSearchLimit,
+                               u32 bandWidth, hitprocessor processor, void* processorInfo);
+alignel*  ref_gapped_extend (seq* seq1, u8* rev1, seq* seq2, u8* rev2, int inhibitTrivial, scoreset* scoring,
+                             segtable* anchors, tback* tb, int allBounds, score yDrop, int trimToPeak,
+                             sthresh scoreThresh, u64 maxPairedBases, int overlyPairedWarn, int overlyPairedKeep);
+
+/* which host objects the device copy currently mirrors */
+static postable* devTable   = NULL;
+static u8*       devTargetV = NULL;
+static unspos    devTargetLen = 0;
+static s8        devCharToBits[256];
+static int       shimVerbose = -1;
+
+static unspos min_target (void)
+	{
+	static long v = -1;
+	if (v < 0) { char* e = getenv ("LZGPU_MIN_TARGET");  v = (e != NULL)? atol(e) : 10000; }
+	return (unspos) v;
+	}
+
+static void note (const char* what, const char* how)
+	{
+	if (shimVerbose < 0) shimVerbose = (getenv ("LZGPU_VERBOSE") != NULL);
+	if (shimVerbose) fprintf (stderr, "[lzgpu] %s: %s\n", what, how);
+	}
+
+static void drop_device_table (void) { devTable = NULL;  devTargetV = NULL;  devTargetLen = 0; }
+
+static int fast_seed (seed* hitSeed, lz_seed_desc* sd)
+	{
+	int i, j, nf, np;
+	if ((hitSeed->type != 'S') || (hitSeed->isHalfweight) || (hitSeed->revComp)
+	 || (hitSeed->next != NULL) || (hitSeed->weight > 28) || (hitSeed->numParts > LZGPU_MAX_PARTS))
+		return false;
+	memset (sd, 0, sizeof(*sd));
+	sd->length = hitSeed->length;  sd->weight_bits = hitSeed->weight;  sd->num_parts = hitSeed->numParts;
+	for (i=0 ; i<hitSeed->numParts ; i++) { sd->shift[i] = hitSeed->shift[i];  sd->mask[i] = hitSeed->mask[i]; }
+	nf = 0;
+	if ((hitSeed->withTrans != 0) && (hitSeed->transFlips != NULL))
+		while (hitSeed->transFlips[nf] != 0) nf++;
+	np = 0;
+	sd->probe_xor[np++] = 0;                                   /* src/seed_search.c:522-549 */
+	if (hitSeed->withTrans == 1)
+		{ for (i=0 ; i<nf ; i++) { if (np >= LZGPU_MAX_PROBES) return false;  sd->probe_xor[np++] = hitSeed->transFlips[i]; } }
+	else if (hitSeed->withTrans >= 2)
+		{
+		for (i=0 ; i<nf ; i++)
+			{
+			if (np >= LZGPU_MAX_PROBES) return false;
+			sd->probe_xor[np++] = hitSeed->transFlips[i];
+			for (j=i+1 ; j<nf ; j++)
+				{ if (np >= LZGPU_MAX_PROBES) return false;  sd->probe_xor[np++] = hitSeed->transFlips[i] ^ hitSeed->transFlips[j]; }
+			}
+		}
+	sd->num_probes = np;
+	return true;
+	}
+
+/* ---- B1 ---- */
+
+postable* build_seed_position_table
+   (seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed, u32 step)
+	{
+	lz_seed_desc sd;
+	postable*    pt;
+	unspos       e = (end == 0)? seq->len : end;
+	int          rc;
+
+	if ((seq->len < min_target()) || (!fast_seed (hitSeed, &sd)) || (seq->fileType == seq_type_qdna)
+	 || (step < 1) || (e <= start) || (e > seq->len))
+		{ note ("table", "reference path");  drop_device_table ();
+		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
+
+	rc = lzgpu_table_prepare (seq->v, seq->len, start, e, upperCharToBits, &sd, step);
+	if (rc < 0) suicidef ("lzgpu_table_prepare: %s", lzgpu_last_error());
+	if (rc > 0)
+		{ note ("table", "declined, reference path");  drop_device_table ();
+		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
+
+	/* host copy in the reference's layout: capsule writer, masking, --tableonly keep working */
+	pt = new_position_table (hitSeed->weight, start, e, step, true, true, false);
+	rc = lzgpu_table_export (pt->last, pt->prev);
+	if (rc != 0) suicidef ("lzgpu_table_export: %s", lzgpu_last_error());
+	devTable = pt;  devTargetV = seq->v;  devTargetLen = seq->len;
+	memcpy (devCharToBits, upperCharToBits, 256);
+	note ("table", "built on the GPU");
+	return pt;
+	}
+
+void free_position_table (postable* pt)
+	{ if (pt == devTable) devTable = NULL;  ref_free_position_table (pt); }
+
+void mask_seed_position_table
+   (postable* pt, seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed)
+	{ if (pt == devTable) drop_device_table ();  ref_mask_seed_position_table (pt, seq, start, end, upperCharToBits, hitSeed); }
+
+void limit_position_table (postable* pt, u32 limit, unspos maxChasm)
+	{ if (pt == devTable) drop_device_table ();  ref_limit_position_table (pt, limit, maxChasm); }
+
+/* ---- B2 ---- */
+
+u64 seed_hit_search
+   (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end, int selfCompare,
+	const s8 upperCharToBits[], seed* hitSeed, u32 searchLimit, u32 reportSearchLimit,
+	u32 bandWidth, hitprocessor processor, void* processorInfo)
+	{
+	hitprocinfo*   hp = (hitprocinfo*) processorInfo;
+	lz_search_args a;
+	lz_hsp*        h = NULL;
+	uint64_t       n = 0, k;
+	u64            basesHit = 0;
+	int            rc;
+
+	if ((pt != devTable) || (devTable == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
+	 || (processor != process_for_simple_hit) || (hp->gfExtend != gfexXDrop)
+	 || (hp->hspThreshold.t != 'S') || (hp->posFilter) || (hp->minMatches >= 0) || (hp->reportEntropy)
+	 || (selfCompare) || (bandWidth != 0) || (searchLimit != 0)
+	 || (seq2->fileType == seq_type_qdna) || (hp->seq1 != seq1) || (hp->seq2 != seq2)
+	 || (memcmp (upperCharToBits, devCharToBits, 256) != 0)
+	 || (seed_search_dbgDumpRawHits) || (seed_search_dbgShowHits) || (seed_search_dbgShowCoverage))
+		{ note ("search", "reference path");
+		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
+		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
+
+	memset (&a, 0, sizeof(a));
+	a.query = seq2->v;  a.qlen = seq2->len;  a.query_slot = -1;
+	a.start = start;    a.end = end;
+	a.sub   = (const int32_t*) hp->scoring->sub;
+	a.xdrop = hp->xDrop;  a.hsp_threshold = hp->hspThreshold.s;  a.entropic = hp->entropicHsp;  a.extend = 1;
+
+	rc = lzgpu_seed_hit_search (&a, &h, &n);
+	if (rc < 0) suicidef ("lzgpu_seed_hit_search: %s", lzgpu_last_error());
+	if (rc > 0)
+		{ note ("search", "declined, reference path");
+		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
+		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
+
+	empty_diag_hash ();                                        /* the reference's side effect, src/seed_search.c:362 */
+	for (k=0 ; k<n ; k++)                                      /* HSPs arrive in discovery order */
+		basesHit += (*hp->reporter) (hp->reporterInfo, h[k].pos1, h[k].pos2, h[k].length, h[k].score);
+	if ((n > 0) && (hp->anchors != NULL) && (*(hp->anchors) != NULL))
+		(*(hp->anchors))->haveScores = true;                   /* src/seed_search.c:2952-2953 */
+	lzgpu_free (h);
+	note ("search", "done on the GPU");
+	return basesHit;
+	}
+
+/* ---- B3 ---- */
+
+alignel* gapped_extend
+   (seq* seq1, u8* rev1, seq* seq2, u8* rev2, int inhibitTrivial, scoreset* scoring, segtable* anchors,
+	tback* tb, int allBounds, score yDrop, int trimToPeak, sthresh scoreThresh,
+	u64 maxPairedBases, int overlyPairedWarn, int overlyPairedKeep)
+	{
+	lz_gapped_args a;
+	lz_segment*    segs;
+	lz_align*      al = NULL;
+	uint32_t*      ops = NULL;
+	uint64_t       n = 0, nops = 0, k;
+	u32            ix, j;
+	alignel*       head = NULL, *last = NULL, *el;
+	int            rc;
+
+	if ((devTargetV == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
+	 || (allBounds) || (!trimToPeak) || (scoreThresh.t != 'S') || (maxPairedBases != 0)
+	 || (seq1->partition.p != NULL) || (seq2->partition.p != NULL) || (seq2->choresFile != NULL)
+	 || (tb == NULL) || (anchors == NULL) || (anchors->len == 0) || (scoring->gapExtend <= 0))
+		{ note ("gapped", "reference path");
+		  return ref_gapped_extend (seq1, rev1, seq2, rev2, inhibitTrivial, scoring, anchors, tb, allBounds, yDrop,
+		                            trimToPeak, scoreThresh, maxPairedBases, overlyPairedWarn, overlyPairedKeep); }
+
+	sort_segments (anchors, qSegmentsByDecreasingScore);       /* batched_segments, src/gapped_extend.c:1675 */
+	segs = (lz_segment*) malloc_or_die ("lzgpu gapped_extend", ((size_t) anchors->len) * sizeof(lz_segment));
+	for (ix=0 ; ix<anchors->len ; ix++)
+		{
+		segs[ix].pos1 = anchors->seg[ix].pos1;  segs[ix].pos2   = anchors->seg[ix].pos2;
+		segs[ix].s    = anchors->seg[ix].s;     segs[ix].length = anchors->seg[ix].length;
+		segs[ix].id   = anchors->seg[ix].id;
+		}
+
+	memset (&a, 0, sizeof(a));
+	a.query = seq2->v;  a.qlen = seq2->len;  a.query_slot = -1;
+	a.sub = (const int32_t*) scoring->sub;  a.gap_open = scoring->gapOpen;  a.gap_extend = scoring->gapExtend;
+	a.ydrop = yDrop;  a.score_thresh = scoreThresh.s;  a.traceback_bytes = tb->size;
+	a.anchors = segs;  a.n_anchors = anchors->len;  a.reduce = 0;   /* reduce_to_points already ran, src/lastz.c:3401 */
+
+	rc = lzgpu_gapped_extend (&a, &al, &n, &ops, &nops);
+	free (segs);
+	if (rc < 0) suicidef ("lzgpu_gapped_extend: %s", lzgpu_last_error());
+	if (rc > 0)
+		{ note ("gapped", "declined, reference path");
+		  return ref_gapped_extend (seq1, rev1, seq2, rev2, inhibitTrivial, scoring, anchors, tb, allBounds, yDrop,
+		                            trimToPeak, scoreThresh, maxPairedBases, overlyPairedWarn, overlyPairedKeep); }
+
+	for (k=0 ; k<n ; k++)                                      /* increasing start, src/gapped_extend.c:1475-1566 */
+		{
+		el = (alignel*) malloc_or_die ("lzgpu alignel", sizeof(alignel));
+		el->next = NULL;  el->isTrivial = false;  el->hspId = 0;
+		el->beg1 = al[k].beg1;  el->beg2 = al[k].beg2;  el->end1 = al[k].end1;  el->end2 = al[k].end2;
+		el->s = al[k].s;  el->seq1 = seq1->v;  el->seq2 = seq2->v;
+		el->script = edit_script_new ();
+		for (j=0 ; j<al[k].script_len ; j++)
+			{
+			uint32_t w = ops[al[k].script_off + j];
+			edit_script_add (&el->script, edit_op_operation(w), edit_op_repeat(w));
+			}
+		if (head == NULL) head = last = el;  else { last->next = el;  last = el; }
+		}
+	lzgpu_free (al);  lzgpu_free (ops);
+	note ("gapped", "done on the GPU");
+	return head;
+	}

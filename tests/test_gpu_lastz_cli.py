@@ -1,0 +1,70 @@
+"""The drop-in claim, end to end: the REFERENCE's own command lines (src/Makefile:208-217,295-400)
+run through oracle/_ref/lastz_gpu -- the reference's host code with its three hot-path entry
+points bound to liblzgpu.so by integration/lzgpu_shim.c -- must give the reference's golden LAV
+byte for byte (modulo the first line of the d-stanza, which holds the command line; that is what
+tools/lav_compare.py ignores too), and must agree byte for byte with the pristine binary on
+MAF / AXT / general output of a fresh synthetic pair.  Needs an MI355X and the prebuilt binaries."""
+import os
+import shutil
+import subprocess
+import pytest
+
+from lastz_amd import seqio
+import helpers as H
+from lavparse import normalize_lav
+
+pytestmark = pytest.mark.gpu
+GPU_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz_gpu")
+REF_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz")
+needs_bins = pytest.mark.skipif(not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)),
+                                reason="oracle/_ref/lastz_gpu not built (needs /root/reference at build time)")
+
+
+@pytest.fixture(scope="module")
+def sandbox(tmp_path_factory):
+    d = tmp_path_factory.mktemp("lz")
+    os.makedirs(d / "test_data"); os.makedirs(d / "src")
+    for f in ("pseudocat.fa", "pseudopig.fa"):
+        shutil.copy(os.path.join(H.GOLDEN, f), d / "test_data" / f)
+    return d
+
+
+def run(binary, args, cwd, env_extra=None):
+    env = dict(os.environ); env.update(env_extra or {})
+    p = subprocess.run([binary] + args, cwd=cwd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p.stdout, p.stderr
+
+
+CASES = [("base_test.default.lav", [], {"table": 1, "search": 6, "gapped": 6}),
+         ("base_test.hsp.lav", ["C=3", "W=8", "T=0"], {"table": 1, "search": 6}),
+         ("base_test.extended.lav", ["C=2", "W=8", "T=0"], {"table": 1, "search": 6}),
+         ("base_test.chained.lav", ["C=1", "W=8", "T=0"], {"table": 1, "search": 6}),
+         ("base_test.hits.lav", ["W=8", "T=0", "--plus", "--nogfextend", "--nogapped"], {"table": 1})]
+
+
+@needs_bins
+@pytest.mark.parametrize("golden,flags,on_gpu", CASES, ids=[c[0] for c in CASES])
+def test_reference_command_lines(sandbox, golden, flags, on_gpu):
+    out, err = run(GPU_BIN, ["../test_data/pseudocat.fa", "../test_data/pseudopig.fa"] + flags, sandbox / "src",
+                   {"LZGPU_VERBOSE": "1"})
+    want = open(os.path.join(H.GOLDEN, golden)).read()
+    assert normalize_lav(out) == normalize_lav(want)
+    for stage, n in on_gpu.items():                 # the GPU path really ran (no quiet reference fallback)
+        assert err.count(f"[lzgpu] {stage}: ") >= n
+        assert err.count(f"[lzgpu] {stage}: done on the GPU") + err.count(f"[lzgpu] {stage}: built on the GPU") >= n, err[-1500:]
+
+
+@needs_bins
+@pytest.mark.parametrize("fmt", ["lav", "maf", "axt", "general"])
+def test_same_bytes_as_pristine_binary(sandbox, fmt):
+    t, q = seqio.synth_pair(1_500_000, 1_200_000, seed=41)
+    seqio.write_fasta(sandbox / "t.fa", [("target", t)])
+    seqio.write_fasta(sandbox / "q.fa", [("q1", q[:700000]), ("q2", q[700000:])])
+    args = ["t.fa", "q.fa", "--format=" + fmt, "--ydrop=9430"]
+    a, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+    b, _ = run(REF_BIN, args, sandbox)
+    assert "[lzgpu] gapped: done on the GPU" in err and "[lzgpu] search: done on the GPU" in err
+    strip = (lambda s: normalize_lav(s)) if fmt == "lav" else (lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#")))
+    assert strip(a) == strip(b)
+    assert len(a) > 10000
