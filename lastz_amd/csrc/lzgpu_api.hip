@@ -288,10 +288,13 @@ extern "C" int lzgpu_table_commit(void)
 {
     LzCtx& c = g_ctx;
     if (!c.target.have_raw || !c.wstart.p) return lz_fail(LZGPU_ERR_STATE, "no table buffers");
-    // the entropy finish needs the target bytes on the host as well
-    c.target.host.resize(c.geom.tlen);
-    if (c.geom.tlen) LZ_HIP(hipMemcpy(c.target.host.data(), c.target.raw_base(), c.geom.tlen, hipMemcpyDeviceToHost));
-    c.target.code_key = 0;
+    // the entropy finish needs the target bytes on the host as well (the target itself does not
+    // change between commits of the same geometry: copied back once)
+    if (c.target.host.size() != c.geom.tlen) {
+        c.target.host.resize(c.geom.tlen);
+        if (c.geom.tlen) LZ_HIP(hipMemcpy(c.target.host.data(), c.target.raw_base(), c.geom.tlen, hipMemcpyDeviceToHost));
+        c.target.code_key = 0;
+    }
     c.have_table = true;
     return 0;
 }
