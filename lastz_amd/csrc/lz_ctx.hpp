@@ -48,6 +48,8 @@ struct LzCtx {
     bool inited = false;
     int  device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // phase B of chunk c overlaps fill/probe/sort of chunk c+1
+    hipEvent_t ev_sorted[2] = { nullptr, nullptr }, ev_extended[2] = { nullptr, nullptr }, ev_init = nullptr;
     std::string last_error;
 
     // ---- target + position table (B1)
@@ -65,6 +67,7 @@ struct LzCtx {
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
     DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
     DevBuf summ_a, summ_b;          // phase-A summaries, travelling with the keys
+    DevBuf keys_b2, summ_b2, bstart2;   // second output set (double buffering across chunks)
     DevBuf sort_tmp, scan_tmp;
     DevBuf bstart;                  // [LZ_DIAG_SIZE+1]
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
@@ -93,6 +96,6 @@ int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys);
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);
 int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n);
-int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart);
+int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart, hipStream_t s);
 int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
-               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters);
+               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

@@ -107,6 +107,12 @@ extern "C" int lzgpu_init(int device_index)
     }
     LZ_HIP(hipSetDevice(device_index));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_sorted[k], hipEventDisableTiming));
+        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_extended[k], hipEventDisableTiming));
+    }
+    LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_init, hipEventDisableTiming));
     g_ctx.device = device_index;
     g_ctx.inited = true;
     return 0;
@@ -117,8 +123,9 @@ extern "C" void lzgpu_shutdown(void)
     LzCtx& c = g_ctx;
     if (!c.inited) return;
     (void)hipStreamSynchronize(c.stream);
+    if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2, &c.bstart2,
                        &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
@@ -126,6 +133,10 @@ extern "C" void lzgpu_shutdown(void)
     c.target.dp.release();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
+    if (c.stream2) (void)hipStreamDestroy(c.stream2);
+    for (int k = 0; k < 2; k++) { if (c.ev_sorted[k]) (void)hipEventDestroy(c.ev_sorted[k]); if (c.ev_extended[k]) (void)hipEventDestroy(c.ev_extended[k]); c.ev_sorted[k] = c.ev_extended[k] = nullptr; }
+    if (c.ev_init) (void)hipEventDestroy(c.ev_init);
+    c.ev_init = nullptr; c.stream2 = nullptr;
     c.stream = nullptr; c.inited = false; c.have_table = false; c.device = -1;
 }
 
@@ -401,6 +412,11 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (a->extend && (rc = c.keys_b.ensure((size_t)max_chunk * 8))) return rc;
         if (a->extend && (rc = c.summ_a.ensure((size_t)max_chunk * 4))) return rc;
         if (a->extend && (rc = c.summ_b.ensure((size_t)max_chunk * 4))) return rc;
+        if (a->extend && chunks.size() > 1) {
+            if ((rc = c.keys_b2.ensure((size_t)max_chunk * 8))) return rc;
+            if ((rc = c.summ_b2.ensure((size_t)max_chunk * 4))) return rc;
+            if ((rc = c.bstart2.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
+        }
     }
     const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
     if (a->extend && (rc = c.hsp_out.ensure((size_t)out_cap * sizeof(LzHspRec)))) return rc;
@@ -412,6 +428,9 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
 
     std::vector<lz_hsp> plain;
     // ---- 3. per chunk: fill -> (phase A probe -> stable bucket sort -> bounds -> phase B bucket-serial pass)
+    LZ_HIP(hipEventRecord(c.ev_init, c.stream));              // state resets above are on stream 1
+    LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_init, 0));
+    size_t ci = 0;
     for (auto& ch : chunks) {
         if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.pk.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
@@ -421,12 +440,25 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
             for (u64 k : hk) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); }
             continue;
         }
+        // Phase B of this chunk runs on stream2 while stream 1 already fills / probes / sorts the next
+        // chunk (two output sets).  Phase B launches are ordered among themselves on stream2 (diagEnd
+        // carries from chunk to chunk); a set is rewritten only after the phase B that read it is done.
+        const int set = (int)(ci & 1);
+        u64* kb = set ? c.keys_b2.as<u64>() : c.keys_b.as<u64>();
+        u32* sb = set ? c.summ_b2.as<u32>() : c.summ_b.as<u32>();
+        u32* bs = set ? c.bstart2.as<u32>() : c.bstart.as<u32>();
         if ((rc = lzk_probe_hits(c, P, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.summ_a.as<u32>()))) return rc;
-        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), c.keys_b.as<u64>(), c.summ_a.as<u32>(), c.summ_b.as<u32>(), ch.nh))) return rc;
-        if ((rc = lzk_bucket_bounds(c, c.keys_b.as<u64>(), ch.nh, c.bstart.as<u32>()))) return rc;
-        if ((rc = lzk_extend(c, P, c.keys_b.as<u64>(), c.summ_b.as<u32>(), c.bstart.as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
-                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters))) return rc;
+        if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
+        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), kb, c.summ_a.as<u32>(), sb, ch.nh))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
+        LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_sorted[set], 0));
+        if ((rc = lzk_bucket_bounds(c, kb, ch.nh, bs, c.stream2))) return rc;
+        if ((rc = lzk_extend(c, P, kb, sb, bs, c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, c.stream2))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_extended[set], c.stream2));
+        ci++;
     }
+    LZ_HIP(hipStreamSynchronize(c.stream2));
 
     u64 hc[3] = { 0, 0, 0 }; u32 n_rec = 0;
     LZ_HIP(hipMemcpyAsync(hc, d_counters, 24, hipMemcpyDeviceToHost, c.stream));

@@ -127,8 +127,7 @@ int lzk_table_build(LzCtx& c)
     if ((rc = c.wpos.ensure((size_t)(nw ? nw : 1) * 4))) return rc;
     LZ_HIP(hipMemcpyAsync(c.wpos.p, c.tb_vals2.p, (size_t)nw * 4, hipMemcpyDeviceToDevice, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
-    c.tb_keys.release(); c.tb_vals.release(); c.tb_keys2.release(); c.tb_vals2.release();
-    return 0;
+    return 0;                                            // scratch stays allocated for the next rebuild
 }
 
 // CSR -> the reference's last[]/prev[] (src/pos_table.h:126-165): one thread per word
@@ -302,12 +301,12 @@ k_bucket_bounds(const u64* __restrict__ keys, u64 n, u32* __restrict__ bstart)
     for (s32 w = bp + 1; w <= b; w++) bstart[w] = (u32)i;
 }
 
-int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart)
+int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart, hipStream_t s)
 {
-    c.timer.begin("k_bucket_bounds", c.stream);
-    hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n + 1 + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+    c.timer.begin("k_bucket_bounds", s);
+    hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n + 1 + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, s,
                        keys, n, bstart);
-    c.timer.end(c.stream);
+    c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
 }
@@ -342,12 +341,12 @@ k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__
 }
 
 int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
-               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters)
+               const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
-    c.timer.begin("k_extend", c.stream);
-    hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, c.stream,
+    c.timer.begin("k_extend", s);
+    hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, s,
                        P, keys, summ, bstart, diag_end, score_tab, out, out_count, out_cap, counters);
-    c.timer.end(c.stream);
+    c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
 }
