@@ -116,6 +116,11 @@ double lzh_hsp_entropy(const u8* s, const u8* t, int len)
         if (s[ix] != t[ix]) continue;
         switch (s[ix]) { case 'A': cA++; break; case 'C': cC++; break; case 'G': cG++; break; case 'T': cT++; break; default: break; }
     }
+    return lzh_entropy_from_counts(cA, cC, cG, cT, len);
+}
+
+double lzh_entropy_from_counts(int cA, int cC, int cG, int cT, int len)
+{
     if (cA + cC + cG + cT < 20) return 1.0;
     double pA = ((double)cA) / ((double)len), pC = ((double)cC) / ((double)len);
     double pG = ((double)cG) / ((double)len), pT = ((double)cT) / ((double)len);
@@ -140,7 +145,7 @@ struct RecKey { u32 pos2, probe, pos1, idx; };
 
 int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
-                    std::vector<lz_hsp>& out)
+                    std::vector<lz_hsp>& out, const u32* match_counts)
 {
     out.clear();
     std::vector<RecKey> order(n_rec);
@@ -165,7 +170,9 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
         u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
         s32 sim = r.score;
         if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
-            double q = lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
+            const u32* mc = match_counts ? match_counts + 4 * (size_t)order[k].idx : nullptr;
+            double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
+                          : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
             sim = (s32)(sim * q);                               // "similarity *= q" on an s32 score
         }
         if (sim < K) continue;

@@ -126,7 +126,7 @@ extern "C" void lzgpu_shutdown(void)
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
     DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2, &c.bstart2,
-                       &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count,
+                       &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); }
@@ -321,6 +321,21 @@ extern "C" int lzgpu_device_copy(void* dst, const void* src, uint64_t bytes)
 
 // ------------------------------------------------------------------------------ B2
 
+#include <chrono>
+struct HostProf {
+    bool on; double t[8]; const char* names[8]; int n = 0;
+    std::chrono::steady_clock::time_point last;
+    HostProf() { on = getenv("LZGPU_HOSTPROF") != nullptr; for (auto& x : t) x = 0; }
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void lap(int k, const char* name) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        t[k] += std::chrono::duration<double, std::milli>(now - last).count(); names[k] = name; if (k >= n) n = k + 1; last = now;
+    }
+    ~HostProf() { if (on) for (int k = 0; k < n; k++) fprintf(stderr, "[lzgpu hostprof] %-28s %10.2f ms total\n", names[k], t[k]); }
+};
+static HostProf g_hp;
+
 extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint64_t* n_out)
 {
     int rc = require_init(); if (rc) return rc;
@@ -329,6 +344,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     *out = nullptr; *n_out = 0;
     if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_prepare has not been called");
 
+    g_hp.start();
     // ---- query
     SeqSlot* qs;
     if (a->query) {
@@ -357,6 +373,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     lzh_make_cls(colc, c.geom.char_to_bits, cls);
     if ((rc = slot_encode(c, *qs, cls, g_cls_q))) return rc;
 
+    g_hp.lap(0, "upload+classes+encode");
     const u32 L = (u32)c.seed.length;
     if (qlen < L) return 0;                                     // src/seed_search.c:486-487
 
@@ -384,6 +401,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     LZ_HIP(hipStreamSynchronize(c.stream));
     c.timer.resolve();
     const u64 total_hits = last_off + last_cnt;
+    g_hp.lap(1, "count+scan (sync)");
 
     // ---- 2. chunk plan: [i0,i1) in query positions with at most hit_capacity hits each.
     // Prefix sums are sampled every S positions (one strided copy); finer values are fetched
@@ -405,6 +423,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if ((rc = lzh_plan_chunks(n, c.hit_capacity, S, off_at, chunks))) return rc;
     if (fetch_err != hipSuccess) return lz_fail(LZGPU_ERR_HIP, "prefix fetch failed: %s", hipGetErrorString(fetch_err));
 
+    g_hp.lap(2, "chunk plan");
     u64 max_chunk = 0;
     for (auto& ch : chunks) if (ch.nh > max_chunk) max_chunk = ch.nh;
     if (max_chunk) {
@@ -458,12 +477,20 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         LZ_HIP(hipEventRecord(c.ev_extended[set], c.stream2));
         ci++;
     }
+    g_hp.lap(3, "chunk loop launches");
     LZ_HIP(hipStreamSynchronize(c.stream2));
+    g_hp.lap(4, "wait for GPU");
 
     u64 hc[3] = { 0, 0, 0 }; u32 n_rec = 0;
     LZ_HIP(hipMemcpyAsync(hc, d_counters, 24, hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipMemcpyAsync(&n_rec, c.hsp_count.p, 4, hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
+    const bool gpu_counts = a->extend && a->entropic && n_rec > 0 && n_rec <= (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
+    if (gpu_counts) {
+        if ((rc = c.hsp_mc.ensure((size_t)n_rec * 16))) return rc;
+        if ((rc = lzk_hsp_match_counts(c, c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), n_rec, n_rec,
+                                       c.target.raw_base(), qs->raw_base(), c.hsp_mc.as<u32>(), c.stream))) return rc;
+    }
     c.timer.resolve();
     c.counters.words += hc[2]; c.counters.raw_hits += total_hits;
     c.counters.extensions += hc[0]; c.counters.bp_extended += hc[1];
@@ -479,15 +506,21 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
 
     // ---- 4. host finish: discovery order, entropy, threshold
     std::vector<LzHspRec> recs(n_rec);
-    if (n_rec) LZ_HIP(hipMemcpy(recs.data(), c.hsp_out.p, (size_t)n_rec * sizeof(LzHspRec), hipMemcpyDeviceToHost));
+    std::vector<u32> mc;
+    if (n_rec) LZ_HIP(hipMemcpyAsync(recs.data(), c.hsp_out.p, (size_t)n_rec * sizeof(LzHspRec), hipMemcpyDeviceToHost, c.stream));
+    if (gpu_counts) { mc.resize((size_t)n_rec * 4); LZ_HIP(hipMemcpyAsync(mc.data(), c.hsp_mc.p, (size_t)n_rec * 16, hipMemcpyDeviceToHost, c.stream)); }
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    c.timer.resolve();
+    g_hp.lap(5, "copy candidates");
     std::vector<lz_hsp> fin;
     if ((rc = lzh_finish_hsps(recs.data(), n_rec, c.target.host.data(), qhost, c.seed, c.geom.char_to_bits,
-                              a->hsp_threshold, a->entropic, fin)))
+                              a->hsp_threshold, a->entropic, fin, gpu_counts ? mc.data() : nullptr)))
         return lz_fail(rc, "internal: candidate HSP is not on a seed hit");
     lz_hsp* res = (lz_hsp*)malloc((fin.size() ? fin.size() : 1) * sizeof(lz_hsp));
     if (!res) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
     if (!fin.empty()) memcpy(res, fin.data(), fin.size() * sizeof(lz_hsp));
     c.counters.hsps += fin.size();
+    g_hp.lap(6, "host finish (order+entropy)");
     *out = res; *n_out = fin.size();
     return 0;
 }

@@ -350,3 +350,39 @@ int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* su
     LZ_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// entropy inputs of the candidate HSPs: per candidate, how many aligned positions carry the
+// same byte 'A' / 'C' / 'G' / 'T' in target and query (compute_entropy counts exactly these,
+// src/dna_utilities.c:2899-2912).  One wave per candidate, lanes stride over the segment.
+__global__ void __launch_bounds__(LZ_TPB)
+k_hsp_match_counts(const LzHspRec* __restrict__ recs, const u32* __restrict__ n_rec, u32 cap,
+                   const u8* __restrict__ traw, const u8* __restrict__ qraw, u32* __restrict__ counts)
+{
+    const u32 wave = (blockIdx.x * LZ_TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    u32 n = *n_rec; if (n > cap) n = cap;
+    if (wave >= n) return;
+    const LzHspRec r = recs[wave];
+    const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+    const u32 s1 = r.end1 - r.length, s2 = (u32)((s32)s1 - diag);
+    u32 cA = 0, cC = 0, cG = 0, cT = 0;
+    for (u32 k = lane; k < r.length; k += 64) {
+        const u32 a = traw[s1 + k], b = qraw[s2 + k];
+        if (a == b) { cA += (a == 'A'); cC += (a == 'C'); cG += (a == 'G'); cT += (a == 'T'); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { cA += __shfl_down(cA, o); cC += __shfl_down(cC, o); cG += __shfl_down(cG, o); cT += __shfl_down(cT, o); }
+    if (lane == 0) { counts[4 * wave] = cA; counts[4 * wave + 1] = cC; counts[4 * wave + 2] = cG; counts[4 * wave + 3] = cT; }
+}
+
+int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
+                         const u8* traw, const u8* qraw, u32* counts, hipStream_t s)
+{
+    if (launch_for == 0) return 0;
+    const u64 threads = (u64)launch_for * 64;
+    c.timer.begin("k_hsp_match_counts", s);
+    hipLaunchKernelGGL(k_hsp_match_counts, dim3((unsigned)((threads + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, s,
+                       recs, n_rec_dev, cap, traw, qraw, counts);
+    c.timer.end(s);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
