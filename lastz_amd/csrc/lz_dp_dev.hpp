@@ -75,6 +75,8 @@ struct LzDpShared {
     s32 cc[LZ_DP_MAXW], dd[LZ_DP_MAXW];   // C[row][col], D[row+1][col]: ring, index col & (MAXW-1)
     u32 mk[LZ_DP_MAXW];                   // mask stamps (= row number), :3706
     u8  lk[LZ_DP_MAXW];                   // traceback link of the current row
+    u8  bb[LZ_DP_MAXW];                   // B (query) score classes of the band's columns, ring by column
+    u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
     // row results of the cross-lane reduction (written by lane 0)
     u32 r_first, r_last, r_ccol; s32 r_cmax;
     // sweep state (written by lane 0)
@@ -83,6 +85,7 @@ struct LzDpShared {
     s32 left_align, right_align, left_seg, right_seg, list_pos;
     u32 tb_used, n_act, done, status, truncated, n_prolong;
     s32 i_last;
+    u32 b_hi, trow_cur;                   // columns < b_hi are staged in bb[]; tbRow[row] of the current row
     u32 max_row, min_col, max_col; u64 cells;
     LzDpActive act[LZ_DP_MAXACT];
 };
@@ -290,16 +293,20 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         // row 0: C[0][0]=0, then insertions while the PREVIOUS column's C is >= -yDrop (note 13)
         u32 n0 = 1; s32 prevc = 0, c = -gapOE;
         while (n0 <= N && prevc >= -Y) { prevc = c; c -= gapE; n0++; }
-        if (n0 + 2 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
+        if (n0 + 2 * LZ_DP_LANES + 8 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
         if (n0 > J.tb_cap || J.row_cap < 2) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; }
         sh.LY = 0; sh.RY = n0; sh.tb_used = n0; sh.cells = n0;
         if (!sh.done) trow[0] = 0;
+        sh.b_hi = 1; sh.trow_cur = 0;
+        while (sh.RY + 2 > sh.b_hi) sh.b_hi += LZ_DP_LANES;     // columns [1, b_hi) are staged by the next phase
         sh.max_col = n0 ? n0 - 1 : 0;
     });
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
             // the mask stamps are row numbers: a previous job's stamps must not survive in the LDS block
             for (u32 k = (u32)lane; k < LZ_DP_MAXW; k += LZ_DP_LANES) sh.mk[k] = 0;
+            for (u32 col = 1 + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES) sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
+            sh.aa[lane] = (1 + (u32)lane <= M) ? (u8)(lz_dp_a(P, J, 1 + (u32)lane) & 31u) : 0;      // rows 1..64
             for (u32 col = (u32)lane; col < sh.RY; col += LZ_DP_LANES) {
                 s32 c = (col == 0) ? 0 : -gapOE - (s32)(col - 1) * gapE;
                 sh.cc[LZ_RING(col)] = c;
@@ -315,6 +322,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         x.phase([&](int lane, LzDpLane&) {
             if (lane != 0) return;
             if (sh.row >= M) { sh.done = 1; return; }
+            while (sh.RY + 2 > sh.b_hi) sh.b_hi += LZ_DP_LANES;     // staged by the previous row's last phase
             sh.row++;
             sh.prevLY = sh.LY;
             lz_dp_update_lr(S, sh, J);
@@ -325,9 +333,9 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             const s32 tb_needed = (s32)width + P.ydrop_tail;
             if ((s64)sh.tb_used + tb_needed >= (s64)P.tb_len) { sh.truncated = 1; sh.done = 1; sh.row--; return; }   // :3640-3661
             if ((u64)sh.tb_used + (u64)tb_needed > (u64)J.tb_cap) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; return; }
-            if (width + (u32)P.ydrop_tail + 4 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
+            if (width + (u32)P.ydrop_tail + 2 * LZ_DP_LANES + 8 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
             if (sh.row + 1 >= J.row_cap) { sh.status = LZ_DP_ROW_SLOT; sh.done = 1; return; }
-            trow[sh.row] = sh.tb_used - sh.LY;                  // tbRow[row], :3662 (u32 wrap intended)
+            trow[sh.row] = sh.trow_cur = sh.tb_used - sh.LY;    // tbRow[row], :3662 (u32 wrap intended)
             sh.ry_iter = sh.RY;
             sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
         });
@@ -335,7 +343,8 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         const u32 row = sh.row, LY0 = sh.LY, RYi = sh.ry_iter, cpl = sh.cpl;
         const s32 best0 = sh.best;
         const bool any_active = sh.n_act != 0;
-        const u32 arow = lz_dp_a(P, J, row) & 31u;
+        const u32 arow = sh.aa[(row - 1) & (LZ_DP_LANES - 1)];
+        const u32 trow_cur = sh.trow_cur;
         const s32* trow_tab = tab + (arow << 5);
 
         // walk 1: block summaries of the insertion recurrence
@@ -345,7 +354,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.c_left_old = (c0 < RYi && c0 > LY0) ? sh.cc[LZ_RING(c0 - 1)] : LZ_DP_NEGINF;
             s32 c_left = r.c_left_old;
             for (u32 col = c0; col < c1; col++) {
-                const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[lz_dp_b(P, J, col) & 31u];
+                const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[sh.bb[LZ_RING(col)]];
                 const s32 d = sh.dd[LZ_RING(col)];
                 c_left = sh.cc[LZ_RING(col)];
                 const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
@@ -370,7 +379,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
             for (u32 col = c0; col < c1; col++) {
-                s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[lz_dp_b(P, J, col) & 31u];
+                s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[sh.bb[LZ_RING(col)]];
                 s32 d = sh.dd[LZ_RING(col)];
                 c_left = sh.cc[LZ_RING(col)];
                 const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
@@ -400,7 +409,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
-            u8* tbr = tb + (u32)(trow[row] + c0);
+            u8* tbr = tb + (u32)(trow_cur + c0);
             for (u32 col = c0; col < c1; col++) {
                 const s32 c = sh.cc[LZ_RING(col)];
                 const u32 link = sh.lk[LZ_RING(col)];
@@ -453,9 +462,19 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
                 const s32 iv = sh.i_last - (s32)k * gapE;
                 sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
-                tb[(u32)(trow[row] + base + k)] = LZ_C_FROM_I;
+                tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
             }
             if (lane == 0 && sh.sentinel) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; }
+            // stage the B classes of the columns the next row may reach, and every 64 rows the next
+            // block of A classes (coalesced loads; the walks then touch LDS only)
+            for (u32 bh = sh.b_hi; sh.RY + 2 > bh; bh += LZ_DP_LANES) {
+                const u32 col = bh + (u32)lane;
+                sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
+            }
+            if ((row & (LZ_DP_LANES - 1)) == 0) {
+                const u32 r2 = row + 1 + (u32)lane;
+                sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
+            }
         });
     }
 
@@ -465,14 +484,18 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         u32 n_ops = 0, status = sh.status;
         if (status == LZ_DP_OK) {
             u32 row = sh.end1, col = sh.end2; u32 prev_op = 0, op;
+            u32 tr_cur = trow[row], tr_prev = row ? trow[row - 1] : 0;
             while (row >= 1 || col > 0) {
-                const u32 link = tb[(u32)(trow[row] + col)];
+                const u32 link = tb[(u32)(tr_cur + col)];
                 op = link & 3u;
                 if (prev_op == LZ_C_FROM_I && (link & LZ_I_EXT)) op = LZ_C_FROM_I;
                 if (prev_op == LZ_C_FROM_D && (link & LZ_D_EXT)) op = LZ_C_FROM_D;
                 if (op == LZ_C_FROM_I)      { col--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 1u); }
-                else if (op == LZ_C_FROM_D) { row--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 2u); }
-                else                        { row--; col--; lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 3u); }
+                else {
+                    if (op == LZ_C_FROM_D)  { row--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 2u); }
+                    else                    { row--; col--; lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 3u); }
+                    tr_cur = tr_prev; tr_prev = row ? trow[row - 1] : 0;      // one row ahead of the dependent byte load
+                }
                 if (status != LZ_DP_OK) break;
                 prev_op = op;
             }
