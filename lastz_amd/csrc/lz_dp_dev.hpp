@@ -27,6 +27,12 @@
 
 #define LZ_DP_LANES   64
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
+#define LZ_DP_BATCH   8               // cells whose LDS reads are issued together in the walks
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LZ_UNROLL _Pragma("unroll")
+#else
+#define LZ_UNROLL
+#endif
 #define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
@@ -347,23 +353,37 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         const u32 trow_cur = sh.trow_cur;
         const s32* trow_tab = tab + (arow << 5);
 
+        // The walks read the sweep row in batches of LZ_DP_BATCH cells: all LDS reads of a batch are
+        // issued before the serial recurrence consumes them (one wave per SIMD has nothing else to
+        // hide LDS latency behind).
         // walk 1: block summaries of the insertion recurrence
         x.phase([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
             r.c_left_old = (c0 < RYi && c0 > LY0) ? sh.cc[LZ_RING(c0 - 1)] : LZ_DP_NEGINF;
             s32 c_left = r.c_left_old;
-            for (u32 col = c0; col < c1; col++) {
-                const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[sh.bb[LZ_RING(col)]];
-                const s32 d = sh.dd[LZ_RING(col)];
-                c_left = sh.cc[LZ_RING(col)];
-                const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
-                if (masked) { A = LZ_DP_NEGINF; K = 0; cut = 1; }
-                else {
-                    const s32 a2 = A - gapE;
-                    const s32 open = (d > cin) ? (LZ_DP_NEGINF - (1 << 24)) : cin - gapOE;
-                    A = open > a2 ? open : a2;
-                    K += gapE;
+            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 rx = LZ_RING(base + k);
+                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; vmk[k] = sh.mk[rx]; vbb[k] = sh.bb[rx];
+                }
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 col = base + k;
+                    if (col < c1) {
+                        const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
+                        const s32 d = vdd[k];
+                        c_left = vcc[k];
+                        const bool masked = any_active && vmk[k] == row;
+                        if (masked) { A = LZ_DP_NEGINF; K = 0; cut = 1; }
+                        else {
+                            const s32 a2 = A - gapE;
+                            const s32 open = (d > cin) ? (LZ_DP_NEGINF - (1 << 24)) : cin - gapOE;
+                            A = open > a2 ? open : a2;
+                            K += gapE;
+                        }
+                    }
                 }
             }
             r.A = A; r.K = K; r.cut = cut;
@@ -378,27 +398,43 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
-            for (u32 col = c0; col < c1; col++) {
-                s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + trow_tab[sh.bb[LZ_RING(col)]];
-                s32 d = sh.dd[LZ_RING(col)];
-                c_left = sh.cc[LZ_RING(col)];
-                const bool masked = any_active && sh.mk[LZ_RING(col)] == row;
-                u32 link;
-                if (masked) { link = 0x80; c = LZ_DP_NEGINF; d = LZ_DP_NEGINF; i = LZ_DP_NEGINF; }
-                else if (d > c || i > c) {
-                    if (d >= i) { c = d; link = LZ_C_FROM_D | LZ_I_EXT | LZ_D_EXT; }
-                    else        { c = i; link = LZ_C_FROM_I | LZ_I_EXT | LZ_D_EXT; }
-                    i -= gapE; d -= gapE;
-                } else {
-                    if (c >= cmax) { cmax = c; ccol = col; }     // candidate for bestScore (later column wins ties)
-                    const s32 c_open = c - gapOE;
-                    d -= gapE;
-                    if (c_open > d) { d = c_open; link = LZ_C_FROM_C; } else link = LZ_C_FROM_C | LZ_D_EXT;
-                    i -= gapE;
-                    if (c_open > i) i = c_open; else link |= LZ_I_EXT;
+            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH], vlk[LZ_DP_BATCH];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 rx = LZ_RING(base + k);
+                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; vmk[k] = sh.mk[rx]; vbb[k] = sh.bb[rx];
                 }
-                if (i < LZ_DP_NEGINF - (1 << 24)) i = LZ_DP_NEGINF - (1 << 24);
-                sh.cc[LZ_RING(col)] = c; sh.dd[LZ_RING(col)] = d; sh.lk[LZ_RING(col)] = (u8)link;
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 col = base + k;
+                    vlk[k] = 0;
+                    if (col < c1) {
+                        s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
+                        s32 d = vdd[k];
+                        c_left = vcc[k];
+                        const bool masked = any_active && vmk[k] == row;
+                        u32 link;
+                        if (masked) { link = 0x80; c = LZ_DP_NEGINF; d = LZ_DP_NEGINF; i = LZ_DP_NEGINF; }
+                        else if (d > c || i > c) {
+                            if (d >= i) { c = d; link = LZ_C_FROM_D | LZ_I_EXT | LZ_D_EXT; }
+                            else        { c = i; link = LZ_C_FROM_I | LZ_I_EXT | LZ_D_EXT; }
+                            i -= gapE; d -= gapE;
+                        } else {
+                            if (c >= cmax) { cmax = c; ccol = col; }     // candidate for bestScore (later column wins ties)
+                            const s32 c_open = c - gapOE;
+                            d -= gapE;
+                            if (c_open > d) { d = c_open; link = LZ_C_FROM_C; } else link = LZ_C_FROM_C | LZ_D_EXT;
+                            i -= gapE;
+                            if (c_open > i) i = c_open; else link |= LZ_I_EXT;
+                        }
+                        if (i < LZ_DP_NEGINF - (1 << 24)) i = LZ_DP_NEGINF - (1 << 24);
+                        vcc[k] = c; vdd[k] = d; vlk[k] = link;
+                    }
+                }
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 col = base + k;
+                    if (col < c1) { const u32 rx = LZ_RING(col); sh.cc[rx] = vcc[k]; sh.dd[rx] = vdd[k]; sh.lk[rx] = (u8)vlk[k]; }
+                }
             }
             r.cand = cmax; r.cand_col = ccol;
         });
@@ -410,20 +446,27 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
             u8* tbr = tb + (u32)(trow_cur + c0);
-            for (u32 col = c0; col < c1; col++) {
-                const s32 c = sh.cc[LZ_RING(col)];
-                const u32 link = sh.lk[LZ_RING(col)];
-                bool live = (link != 0x80) && (c >= rb - Y);
-                if (live) {
-                    if (first == 0xFFFFFFFFu) first = col;
-                    last = col;
-                    if ((link & 3u) == LZ_C_FROM_C && c > rb) rb = c;
-                    *tbr = (u8)link;
-                } else {
-                    sh.cc[LZ_RING(col)] = LZ_DP_NEGINF; sh.dd[LZ_RING(col)] = LZ_DP_NEGINF;
-                    *tbr = 0;
+            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH]; u32 vlk[LZ_DP_BATCH];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) { const u32 rx = LZ_RING(base + k); vcc[k] = sh.cc[rx]; vlk[k] = sh.lk[rx]; }
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                    const u32 col = base + k;
+                    if (col < c1) {
+                        const s32 c = vcc[k];
+                        const u32 link = vlk[k];
+                        const bool live = (link != 0x80) && (c >= rb - Y);
+                        if (live) {
+                            if (first == 0xFFFFFFFFu) first = col;
+                            last = col;
+                            if ((link & 3u) == LZ_C_FROM_C && c > rb) rb = c;
+                            tbr[k] = (u8)link;
+                        } else {
+                            sh.cc[LZ_RING(col)] = LZ_DP_NEGINF; sh.dd[LZ_RING(col)] = LZ_DP_NEGINF;
+                            tbr[k] = 0;
+                        }
+                    }
                 }
-                tbr++;
+                tbr += LZ_DP_BATCH;
             }
             r.first = first; r.last = last;
         });
