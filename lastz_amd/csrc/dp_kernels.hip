@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <vector>
 #include <algorithm>
 #include "lz_ctx.hpp"
@@ -129,6 +130,14 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipStreamSynchronize(c.stream));
         c.timer.resolve();
         for (u32 id : ids) res[id] = all[id];
+        if (getenv("LZGPU_DPPROF")) {
+            u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0;
+            for (u32 id : ids) { sum_r += all[id].t_rows; sum_t += all[id].t_trace;
+                                 if (all[id].t_rows + all[id].t_trace > mr) { mr = all[id].t_rows + all[id].t_trace; tr = all[id].t_rows; tt = all[id].t_trace; rows = all[id].max_row; cells = all[id].cells; } }
+            fprintf(stderr, "[lzgpu dpprof] launch of %zu DPs: longest = %u rows, %llu cells, sweep %llu ticks (%.0f/row), traceback %llu ticks; all DPs: sweep %llu, traceback %llu ticks\n",
+                    ids.size(), rows, (unsigned long long)cells, (unsigned long long)tr, rows ? (double)tr / rows : 0.0, (unsigned long long)tt,
+                    (unsigned long long)sum_r, (unsigned long long)sum_t);
+        }
         return 0;
     }
 

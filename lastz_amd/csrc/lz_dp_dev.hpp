@@ -65,6 +65,7 @@ struct LzDpResult {
     s32 score; u32 end1, end2; u32 n_ops; u32 status; u32 truncated;
     u32 max_row, min_col, max_col;      // explored region in DP coordinates (row 0..max_row)
     u32 tb_used; u64 cells;
+    u64 t_rows, t_trace;                // shader-clock ticks spent in the row sweep / the traceback (0 off-device)
 };
 
 struct LzDpParams {                     // per batch
@@ -91,8 +92,10 @@ struct LzDpShared {
     s32 left_align, right_align, left_seg, right_seg, list_pos;
     u32 tb_used, n_act, done, status, truncated, n_prolong;
     s32 i_last;
+    u32 next_act_row;                     // row at which aligns[order[list_pos]] becomes active
     u32 b_hi, trow_cur;                   // columns < b_hi are staged in bb[]; tbRow[row] of the current row
     u32 max_row, min_col, max_col; u64 cells;
+    LzDpSeg lcur, rcur;                   // copies of segs[left_seg] / segs[right_seg]
     LzDpActive act[LZ_DP_MAXACT];
 };
 
@@ -127,6 +130,11 @@ LZ_HD u32 lz_dp_a(const LzDpParams& P, const LzDpJob& J, u32 row)
 LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
 { return J.reversed ? P.qdp[(s64)J.anchor2 + 1 - (s64)col] : P.qdp[(s64)J.anchor2 + (s64)col]; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LZ_CLOCK() ((u64)__builtin_readcyclecounter())
+#else
+#define LZ_CLOCK() ((u64)0)
+#endif
 #define LZ_SDIFF(a, b) (((s32)(a)) - ((s32)(b)))
 #define LZ_RING(c) ((c) & (LZ_DP_MAXW - 1))
 
@@ -162,31 +170,33 @@ LZ_HD s32 lz_dp_prev_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, 
 
 LZ_HD u32 lz_dp_special_min(u32 ry, s32 r) { if (r <= 0) return 0; if ((u32)r < ry) return (u32)r; return ry; }
 
-// update_LR_bounds, src/gapped_extend.c:4588-4700 (lane 0)
+// update_LR_bounds, src/gapped_extend.c:4588-4700 (lane 0).  The bounding segments change every
+// few hundred rows but are consulted on every row: their fields are kept in LDS (sh.lcur / sh.rcur)
+// and re-read from HBM only when next/prev_sweep_seg moves to another segment.
 LZ_HD void lz_dp_update_lr(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
 {
     s32 L = sh.L, R = sh.R; u32 LY = sh.LY, RY = sh.RY;
     const u32 row = sh.row, a1 = J.anchor1, a2 = J.anchor2;
     if (!J.reversed) {
         if (sh.left_seg >= 0) {
-            if (S.segs[sh.left_seg].e1 >= row + a1) { if (S.segs[sh.left_seg].type == LZ_DIAG_SEG) L++; }
-            else L = lz_dp_next_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) + 1;
+            if (sh.lcur.e1 >= row + a1) { if (sh.lcur.type == LZ_DIAG_SEG) L++; }
+            else { L = lz_dp_next_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) + 1; if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg]; }
         }
         if (sh.left_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
         if (sh.right_seg >= 0) {
-            if (S.segs[sh.right_seg].e1 >= row + a1) { if (S.segs[sh.right_seg].type == LZ_DIAG_SEG) R++; }
-            else R = lz_dp_next_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) - 1;
+            if (sh.rcur.e1 >= row + a1) { if (sh.rcur.type == LZ_DIAG_SEG) R++; }
+            else { R = lz_dp_next_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) - 1; if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg]; }
         }
         if (sh.right_seg >= 0) RY = lz_dp_special_min(RY, R);
     } else {
         if (sh.right_seg >= 0) {
-            if (S.segs[sh.right_seg].b1 <= a1 - row) { if (S.segs[sh.right_seg].type == LZ_DIAG_SEG) L++; }
-            else L = lz_dp_prev_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) + 1;
+            if (sh.rcur.b1 <= a1 - row) { if (sh.rcur.type == LZ_DIAG_SEG) L++; }
+            else { L = lz_dp_prev_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) + 1; if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg]; }
         }
         if (sh.right_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
         if (sh.left_seg >= 0) {
-            if (S.segs[sh.left_seg].b1 <= a1 - row) { if (S.segs[sh.left_seg].type == LZ_DIAG_SEG) R++; }
-            else R = lz_dp_prev_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) - 1;
+            if (sh.lcur.b1 <= a1 - row) { if (sh.lcur.type == LZ_DIAG_SEG) R++; }
+            else { R = lz_dp_prev_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) - 1; if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg]; }
         }
         if (sh.left_seg >= 0) RY = lz_dp_special_min(RY, R);
     }
@@ -211,6 +221,15 @@ LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJ
     }
 }
 
+// row at which the alignment at the head of the above/below list reaches the sweep (or none)
+LZ_HD void lz_dp_peek_list(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+{
+    if (sh.list_pos < 0 || sh.list_pos >= S.n_aligns) { sh.list_pos = -1; sh.next_act_row = 0xFFFFFFFFu; return; }
+    const s32* order = J.reversed ? S.oed : S.obi;
+    const LzDpAlign& al = S.aligns[order[sh.list_pos]];
+    sh.next_act_row = J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1);
+}
+
 // update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
 LZ_HD void lz_dp_update_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
 {
@@ -233,21 +252,18 @@ LZ_HD void lz_dp_update_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDp
             } else act.filter = 1;
         }
     }
-    // alignments the sweep row now reaches (the reference prepends; order within the list is immaterial)
-    if (sh.list_pos >= 0) {
+    // alignments the sweep row now reaches (the reference prepends; order within the list is
+    // immaterial).  The row at which the head of the list starts is cached (sh.next_act_row).
+    while (sh.list_pos >= 0 && sh.next_act_row == row) {
         const s32* order = J.reversed ? S.oed : S.obi;
-        while (sh.list_pos >= 0 && sh.list_pos < S.n_aligns) {
-            const LzDpAlign& al = S.aligns[order[sh.list_pos]];
-            bool hit = J.reversed ? (J.anchor1 - al.end1 == row) : (al.pos1 - J.anchor1 == row);
-            if (!hit) break;
-            if (sh.n_act >= LZ_DP_MAXACT) { sh.status = LZ_DP_ACT_SLOT; sh.done = 1; return; }
-            LzDpActive& act = sh.act[sh.n_act++];
-            act.filter = 0; act.align = order[sh.list_pos];
-            act.seg = J.reversed ? al.last_seg : al.first_seg;
-            lz_dp_build_active(S, sh, J, act);
-            sh.list_pos++;
-        }
-        if (sh.list_pos >= S.n_aligns) sh.list_pos = -1;
+        const LzDpAlign& al = S.aligns[order[sh.list_pos]];
+        if (sh.n_act >= LZ_DP_MAXACT) { sh.status = LZ_DP_ACT_SLOT; sh.done = 1; return; }
+        LzDpActive& act = sh.act[sh.n_act++];
+        act.filter = 0; act.align = order[sh.list_pos];
+        act.seg = J.reversed ? al.last_seg : al.first_seg;
+        lz_dp_build_active(S, sh, J, act);
+        sh.list_pos++;
+        lz_dp_peek_list(S, sh, J);
     }
     u32 w = 0;                                                 // filter_active_segs(&active, 0)
     for (u32 k = 0; k < sh.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
@@ -275,10 +291,11 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
             if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
-                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; } });
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; } });
         return;
     }
 
+    const u64 t0 = LZ_CLOCK();
     // ---- set-up + row 0 (:3500-3605)
     x.phase([&](int lane, LzDpLane&) {
         if (lane != 0) return;
@@ -292,7 +309,10 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         }
         sh.L = L; sh.R = R;
         sh.left_align = J.left_align; sh.right_align = J.right_align; sh.left_seg = J.left_seg; sh.right_seg = J.right_seg;
+        if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg];
+        if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg];
         sh.list_pos = J.list_start; sh.n_act = 0;
+        lz_dp_peek_list(S, sh, J);
         sh.done = 0; sh.status = LZ_DP_OK; sh.truncated = 0;
         sh.best = 0; sh.end1 = sh.end2 = 0; sh.row = 0; sh.cells = 0;
         sh.max_row = 0; sh.min_col = 0; sh.max_col = 0;
@@ -524,6 +544,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     // ---- traceback (:3847-3859) and result (lane 0)
     x.phase([&](int lane, LzDpLane&) {
         if (lane != 0) return;
+        const u64 t1 = LZ_CLOCK();
         u32 n_ops = 0, status = sh.status;
         if (status == LZ_DP_OK) {
             u32 row = sh.end1, col = sh.end2; u32 prev_op = 0, op;
@@ -547,5 +568,6 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         res->status = status; res->truncated = sh.truncated;
         res->max_row = sh.max_row; res->min_col = sh.min_col; res->max_col = sh.max_col;
         res->tb_used = sh.tb_used; res->cells = sh.cells;
+        res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
     });
 }
