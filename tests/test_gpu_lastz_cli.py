@@ -24,7 +24,7 @@ needs_bins = pytest.mark.skipif(not (os.path.exists(GPU_BIN) and os.path.exists(
 def sandbox(tmp_path_factory):
     d = tmp_path_factory.mktemp("lz")
     os.makedirs(d / "test_data"); os.makedirs(d / "src")
-    for f in ("pseudocat.fa", "pseudopig.fa"):
+    for f in ("pseudocat.fa", "pseudopig.fa", "aglobin.2bit"):
         shutil.copy(os.path.join(H.GOLDEN, f), d / "test_data" / f)
     return d
 
@@ -40,6 +40,7 @@ CASES = [("base_test.default.lav", [], {"table": 1, "search": 6, "gapped": 6}),
          ("base_test.hsp.lav", ["C=3", "W=8", "T=0"], {"table": 1, "search": 6}),
          ("base_test.extended.lav", ["C=2", "W=8", "T=0"], {"table": 1, "search": 6}),
          ("base_test.chained.lav", ["C=1", "W=8", "T=0"], {"table": 1, "search": 6}),
+         ("base_test.interpolated.lav", ["C=2", "W=8", "T=0", "H=2200"], {"table": 1, "search": 6}),     # tweener second pass
          ("base_test.hits.lav", ["W=8", "T=0", "--plus", "--nogfextend", "--nogapped"], {"table": 1})]
 
 
@@ -68,3 +69,41 @@ def test_same_bytes_as_pristine_binary(sandbox, fmt):
     strip = (lambda s: normalize_lav(s)) if fmt == "lav" else (lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#")))
     assert strip(a) == strip(b)
     assert len(a) > 2000
+
+
+@needs_bins
+def test_gapped_stage_alone_from_saved_segments(sandbox):
+    """src/Makefile:384-400: HSPs saved with --format=segments, gapped stage run from --segments=<file>
+    (B3 in isolation) must give base_test.default.lav"""
+    src = sandbox / "src"
+    hsps, _ = run(GPU_BIN, ["../test_data/pseudocat.fa", "../test_data/pseudopig.fa", "--nogapped", "--format=segments"], src)
+    open(src / "hsps.segments", "w").write(hsps)
+    out, err = run(GPU_BIN, ["../test_data/pseudocat.fa", "../test_data/pseudopig.fa", "--segments=hsps.segments"], src,
+                   {"LZGPU_VERBOSE": "1"})
+    want = open(os.path.join(H.GOLDEN, "base_test.default.lav")).read()
+    drop = lambda s: "\n".join(l for l in normalize_lav(s).split("\n"))
+    assert drop(out) == drop(want)
+    assert err.count("[lzgpu] gapped: done on the GPU") >= 6
+
+
+@needs_bins
+@pytest.mark.parametrize("args", [["../test_data/aglobin.2bit/human", "../test_data/aglobin.2bit/cow"],
+                                  ["../test_data/aglobin.2bit/human[20000..60000]", "../test_data/aglobin.2bit/cow", "--step=3", "--seed=match12"],
+                                  ["../test_data/aglobin.2bit/human", "../test_data/aglobin.2bit/cow", "--notransition", "--nogapped", "--format=maf"],
+                                  ["../test_data/aglobin.2bit/cow", "../test_data/aglobin.2bit/human", "--hspthresh=2200", "--ydrop=5000", "--gappedthresh=4000", "--format=axt"],
+                                  ["../test_data/aglobin.2bit/human", "../test_data/aglobin.2bit/human", "--self", "--chain"]],
+                         ids=["human-cow", "subrange-step3-match12", "notransition-maf", "thresholds-axt", "self-chain"])
+def test_real_dna_soft_masked_2bit(sandbox, args):
+    """aglobin.2bit (the reference's real-DNA fixture: lower-case = soft-masked): the GPU-bound binary and
+    the pristine binary give the same bytes for a spread of option sets; self-alignment (BASELINE.json
+    config 1) is outside the fast path and must still be right (reference routines via the shim)."""
+    src = sandbox / "src"
+    a, err = run(GPU_BIN, args, src, {"LZGPU_VERBOSE": "1"})
+    b, _ = run(REF_BIN, args, src)
+    na = normalize_lav(a) if "--format" not in " ".join(args) else a
+    nb = normalize_lav(b) if "--format" not in " ".join(args) else b
+    strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+    assert strip(na) == strip(nb)
+    assert len(a) > 500
+    if "--self" not in args:
+        assert "[lzgpu] table: built on the GPU" in err and "[lzgpu] search: done on the GPU" in err
