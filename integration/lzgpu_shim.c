@@ -101,7 +101,7 @@ postable* build_seed_position_table
 
 	if ((seq->len < min_target()) || (!fast_seed (hitSeed, &sd)) || (seq->fileType == seq_type_qdna)
 	 || (step < 1) || (e <= start) || (e > seq->len))
-		{ note ("table", "reference path");  drop_device_table ();
+		{ note ("table", "reference path");       /* (e.g. the tweener's small windows; the device keeps the main table) */
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
 
 	rc = lzgpu_table_prepare (seq->v, seq->len, start, e, upperCharToBits, &sd, step);
