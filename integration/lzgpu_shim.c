@@ -99,8 +99,11 @@ postable* build_seed_position_table
 	unspos       e = (end == 0)? seq->len : end;
 	int          rc;
 
+	/* the device holds ONE table: while the main target's table is live, any other table (the
+	   tweener's 7-mer tables on <=20 kbp windows, src/tweener.c:791) is built by the reference */
 	if ((seq->len < min_target()) || (!fast_seed (hitSeed, &sd)) || (seq->fileType == seq_type_qdna)
-	 || (step < 1) || (e <= start) || (e > seq->len))
+	 || (step < 1) || (e <= start) || (e > seq->len)
+	 || ((devTable != NULL) && (seq->v != devTargetV)))
 		{ note ("table", "reference path");       /* (e.g. the tweener's small windows; the device keeps the main table) */
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
 
