@@ -178,6 +178,10 @@ typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46   
 /* Alignments in the reference's output order (increasing start in the target,
  * src/gapped_extend.c:1475-1566).  ops are the reference's editop words:
  * (repeat<<2)|op with op 1=ins 2=del 3=sub (src/edit_script.h:48-70). */
+/* The target of lzgpu_gapped_extend is the sequence last given to lzgpu_table_prepare; a caller that runs
+ * the gapped stage without a seed search (lastz --segments=<file>, src/lastz.c:3036-3050) uploads it with
+ * lzgpu_target_upload instead (this discards any position table held on the device). */
+int lzgpu_target_upload(const uint8_t* t, uint32_t tlen);
 int lzgpu_gapped_extend(const lz_gapped_args* args, lz_align** out, uint64_t* n_out,
                         uint32_t** ops, uint64_t* n_ops);
 

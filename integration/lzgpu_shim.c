@@ -197,6 +197,15 @@ alignel* gapped_extend
 	alignel*       head = NULL, *last = NULL, *el;
 	int            rc;
 
+	/* gapped stage without a seed search (--segments=<file>): put the target on the device first */
+	if ((devTable == NULL) && ((seq1->v != devTargetV) || (seq1->len != devTargetLen))
+	 && (seq1->len >= min_target()) && (seq1->fileType != seq_type_qdna))
+		{
+		rc = lzgpu_target_upload (seq1->v, seq1->len);
+		if (rc < 0) suicidef ("lzgpu_target_upload: %s", lzgpu_last_error());
+		if (rc == 0) { devTargetV = seq1->v;  devTargetLen = seq1->len; }
+		}
+
 	if ((devTargetV == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
 	 || (allBounds) || (!trimToPeak) || (scoreThresh.t != 'S') || (maxPairedBases != 0)
 	 || (seq1->partition.p != NULL) || (seq2->partition.p != NULL) || (seq2->choresFile != NULL)

@@ -234,7 +234,8 @@ extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint
     if (!a || !out || !n_out || !ops || !n_ops || !a->sub) return lz_fail(LZGPU_ERR_ARG, "null argument");
     *out = nullptr; *n_out = 0; *ops = nullptr; *n_ops = 0;
     if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
-    if (!c.have_table || c.target.host.empty()) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_prepare has not been called (the target is taken from it)");
+    if (!c.target.have_raw || c.target.host.size() != c.target.len || c.target.len != c.geom.tlen)
+        return lz_fail(LZGPU_ERR_STATE, "no target on the device (lzgpu_table_prepare / lzgpu_target_upload)");
 
     // ---- query
     SeqSlot* qs; int rc;

@@ -229,6 +229,18 @@ extern "C" int lzgpu_table_prepare(const uint8_t* t, uint32_t tlen, uint32_t sta
     return 0;
 }
 
+extern "C" int lzgpu_target_upload(const uint8_t* t, uint32_t tlen)
+{
+    int rc = require_init(); if (rc) return rc;
+    LzCtx& c = g_ctx;
+    if (!t) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    if (tlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+    c.have_table = false;
+    memset(&c.geom, 0, sizeof(c.geom));
+    c.geom.tlen = tlen;
+    return slot_upload(c, c.target, t, tlen, true);
+}
+
 extern "C" int lzgpu_table_rebuild(void)
 {
     LzCtx& c = g_ctx;

@@ -56,7 +56,7 @@ ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end
 EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdown", "lzgpu_free",
            "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_device_copy",
-           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_gapped_extend",
+           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window"]
 
@@ -102,6 +102,7 @@ class Lib:
             self.L.lzgpu_table_buffers.argtypes = [C.POINTER(C.c_void_p * 3), C.POINTER(C.c_uint64 * 3)]
             self.L.lzgpu_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
             self.L.lzgpu_query_upload.argtypes = [C.c_int32, C.c_void_p, C.c_uint32]
+            self.L.lzgpu_target_upload.argtypes = [C.c_void_p, C.c_uint32]
             self.L.lzgpu_gapped_extend.argtypes = [C.POINTER(GappedArgs), C.POINTER(C.c_void_p),
                                                    C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
                                                    C.POINTER(C.c_uint64)]
@@ -207,6 +208,10 @@ class Lib:
             C.memmove(_ptr(res), out, n.value * HSP_DTYPE.itemsize)
         self._f("free")(out)
         return res
+
+    def target_upload(self, t):
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        self._check(self.L.lzgpu_target_upload(_ptr(t), len(t)), "lzgpu_target_upload")
 
     # ---- B3
     def gapped_extend(self, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400,
