@@ -91,7 +91,7 @@ def test_gapped_stage_alone_from_saved_segments(sandbox):
                                   ["../test_data/aglobin.2bit/human[20000..60000]", "../test_data/aglobin.2bit/cow", "--step=3", "--seed=match12"],
                                   ["../test_data/aglobin.2bit/human", "../test_data/aglobin.2bit/cow", "--notransition", "--nogapped", "--format=maf"],
                                   ["../test_data/aglobin.2bit/cow", "../test_data/aglobin.2bit/human", "--hspthresh=2200", "--ydrop=5000", "--gappedthresh=4000", "--format=axt"],
-                                  ["../test_data/aglobin.2bit/human", "../test_data/aglobin.2bit/human", "--self", "--chain"]],
+                                  ["../test_data/aglobin.2bit/human", "--self", "--chain"]],
                          ids=["human-cow", "subrange-step3-match12", "notransition-maf", "thresholds-axt", "self-chain"])
 def test_real_dna_soft_masked_2bit(sandbox, args):
     """aglobin.2bit (the reference's real-DNA fixture: lower-case = soft-masked): the GPU-bound binary and
