@@ -73,7 +73,7 @@ struct LzCtx {
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
     DevBuf score_tab;               // [32*32] s32
     DevBuf hsp_out, hsp_count;      // candidates + counter
-    DevBuf hsp_mc;                  // [n][4] match counts of the candidates (entropy inputs)
+    DevBuf hsp_mc;                  // [n][5]: A/C/G/T match counts of the candidates (entropy inputs) + probe index
     DevBuf dev_counters;            // u64[8]
     DevBuf tb_keys, tb_vals, tb_keys2, tb_vals2;   // table build scratch
     u64 hit_capacity = (1ull << 28);
@@ -96,7 +96,7 @@ int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk,
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
-                         const u8* traw, const u8* qraw, u32* counts, hipStream_t s);
+                         const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);
 int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n);
 int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart, hipStream_t s);

@@ -151,11 +151,14 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
     std::vector<RecKey> order(n_rec);
     for (u32 i = 0; i < n_rec; i++) {
         u32 pt = 0, pq = 0, probe = 0;
-        if (!host_window_word(thost, recs[i].seed_pos1, sd, ctb, pt) ||
-            !host_window_word(qhost, recs[i].seed_pos2, sd, ctb, pq)) return LZGPU_ERR_STATE;
-        u32 x = pt ^ pq;
-        for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break;
-        if (probe == (u32)sd.nprobes) return LZGPU_ERR_STATE;
+        if (match_counts) probe = match_counts[5 * (size_t)i + 4];
+        else {
+            if (!host_window_word(thost, recs[i].seed_pos1, sd, ctb, pt) ||
+                !host_window_word(qhost, recs[i].seed_pos2, sd, ctb, pq)) return LZGPU_ERR_STATE;
+            u32 x = pt ^ pq;
+            for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break;
+        }
+        if (probe >= (u32)sd.nprobes) return LZGPU_ERR_STATE;
         order[i] = { recs[i].seed_pos2, probe, recs[i].seed_pos1, i };
     }
     std::sort(order.begin(), order.end(), [](const RecKey& x, const RecKey& y) {
@@ -170,7 +173,7 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
         u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
         s32 sim = r.score;
         if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
-            const u32* mc = match_counts ? match_counts + 4 * (size_t)order[k].idx : nullptr;
+            const u32* mc = match_counts ? match_counts + 5 * (size_t)order[k].idx : nullptr;
             double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
                           : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
             sim = (s32)(sim * q);                               // "similarity *= q" on an s32 score

@@ -48,9 +48,10 @@ int lzh_plan_chunks(u32 n, u64 cap, u32 S, OffAt&& off_at, std::vector<LzChunk>&
 // Candidate HSPs (any order) -> what the reference's reporter sees, in discovery order:
 // (query position of the seed hit ascending, probe index, target position descending), entropy
 // adjustment (src/seed_search.c:2851-2874) and the score threshold (:2907-2933).
-// match_counts (optional, [n_rec][4]): per candidate the number of positions where target and query
+// match_counts (optional, [n_rec][5]): per candidate the number of positions where target and query
 // carry the same byte 'A','C','G','T' -- the only thing the entropy needs from the sequences
-// (src/dna_utilities.c:2899-2912); when NULL they are counted here from thost/qhost.
+// (src/dna_utilities.c:2899-2912) -- and the index of the probe that produced the seed hit; when NULL
+// both are derived here from thost/qhost.
 int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
                     std::vector<lz_hsp>& out, const u32* match_counts = nullptr);

@@ -335,7 +335,7 @@ extern "C" int lzgpu_device_copy(void* dst, const void* src, uint64_t bytes)
 
 #include <chrono>
 struct HostProf {
-    bool on; double t[8]; const char* names[8]; int n = 0;
+    bool on; double t[12]; const char* names[12]; int n = 0;
     std::chrono::steady_clock::time_point last;
     HostProf() { on = getenv("LZGPU_HOSTPROF") != nullptr; for (auto& x : t) x = 0; }
     void start() { if (on) last = std::chrono::steady_clock::now(); }
@@ -374,12 +374,14 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if (hi <= lo) return lz_fail(LZGPU_ERR_ARG, "in seed_hit_search(), interval is void (%u-%u)", lo, hi);
     if (hi > qlen) return lz_fail(LZGPU_ERR_ARG, "in seed_hit_search(), interval end is bad (%u>%u)", hi, qlen);
 
+    g_hp.lap(7, "query slot");
     // ---- scoring classes, codes
     u8 rowc[256], colc[256], cls[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
     if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
     if ((rc = c.score_tab.ensure(sizeof(tab)))) return rc;
     LZ_HIP(hipMemcpyAsync(c.score_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
+    g_hp.lap(8, "score classes + table upload");
     lzh_make_cls(rowc, c.geom.char_to_bits, cls);
     if ((rc = slot_encode(c, c.target, cls, g_cls_t))) return rc;
     lzh_make_cls(colc, c.geom.char_to_bits, cls);
@@ -497,11 +499,12 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     LZ_HIP(hipMemcpyAsync(hc, d_counters, 24, hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipMemcpyAsync(&n_rec, c.hsp_count.p, 4, hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
-    const bool gpu_counts = a->extend && a->entropic && n_rec > 0 && n_rec <= (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
+    const bool gpu_counts = a->extend && n_rec > 0 && n_rec <= (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
     if (gpu_counts) {
-        if ((rc = c.hsp_mc.ensure((size_t)n_rec * 16))) return rc;
+        if ((rc = c.hsp_mc.ensure((size_t)n_rec * 20))) return rc;
         if ((rc = lzk_hsp_match_counts(c, c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), n_rec, n_rec,
-                                       c.target.raw_base(), qs->raw_base(), c.hsp_mc.as<u32>(), c.stream))) return rc;
+                                       c.target.raw_base(), qs->raw_base(), c.target.code_base(), qs->code_base(),
+                                       c.hsp_mc.as<u32>(), c.stream))) return rc;
     }
     c.timer.resolve();
     c.counters.words += hc[2]; c.counters.raw_hits += total_hits;
@@ -520,7 +523,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     std::vector<LzHspRec> recs(n_rec);
     std::vector<u32> mc;
     if (n_rec) LZ_HIP(hipMemcpyAsync(recs.data(), c.hsp_out.p, (size_t)n_rec * sizeof(LzHspRec), hipMemcpyDeviceToHost, c.stream));
-    if (gpu_counts) { mc.resize((size_t)n_rec * 4); LZ_HIP(hipMemcpyAsync(mc.data(), c.hsp_mc.p, (size_t)n_rec * 16, hipMemcpyDeviceToHost, c.stream)); }
+    if (gpu_counts) { mc.resize((size_t)n_rec * 5); LZ_HIP(hipMemcpyAsync(mc.data(), c.hsp_mc.p, (size_t)n_rec * 20, hipMemcpyDeviceToHost, c.stream)); }
     LZ_HIP(hipStreamSynchronize(c.stream));
     c.timer.resolve();
     g_hp.lap(5, "copy candidates");

@@ -357,7 +357,8 @@ int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* su
 // src/dna_utilities.c:2899-2912).  One wave per candidate, lanes stride over the segment.
 __global__ void __launch_bounds__(LZ_TPB)
 k_hsp_match_counts(const LzHspRec* __restrict__ recs, const u32* __restrict__ n_rec, u32 cap,
-                   const u8* __restrict__ traw, const u8* __restrict__ qraw, u32* __restrict__ counts)
+                   const u8* __restrict__ traw, const u8* __restrict__ qraw,
+                   const u8* __restrict__ tcode, const u8* __restrict__ qcode, LzSeedDev sd, u32* __restrict__ counts)
 {
     const u32 wave = (blockIdx.x * LZ_TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     u32 n = *n_rec; if (n > cap) n = cap;
@@ -371,17 +372,27 @@ k_hsp_match_counts(const LzHspRec* __restrict__ recs, const u32* __restrict__ n_
         if (a == b) { cA += (a == 'A'); cC += (a == 'C'); cG += (a == 'G'); cT += (a == 'T'); }
     }
     for (int o = 32; o > 0; o >>= 1) { cA += __shfl_down(cA, o); cC += __shfl_down(cC, o); cG += __shfl_down(cG, o); cT += __shfl_down(cT, o); }
-    if (lane == 0) { counts[4 * wave] = cA; counts[4 * wave + 1] = cC; counts[4 * wave + 2] = cG; counts[4 * wave + 3] = cT; }
+    if (lane == 0) {
+        // which probe produced the seed hit (its discovery rank inside a query position): the XOR of the
+        // two packed words is one of the probe masks (src/seed_search.c:522-549)
+        u32 pt = 0, pq = 0, probe = 0xFFFFFFFFu;
+        if (lz_window_word(tcode, r.seed_pos1, sd, pt) && lz_window_word(qcode, r.seed_pos2, sd, pq)) {
+            const u32 x = pt ^ pq;
+            for (int p = 0; p < sd.nprobes; p++) if (sd.probe_xor[p] == x) { probe = (u32)p; break; }
+        }
+        u32* o = counts + 5 * (size_t)wave;
+        o[0] = cA; o[1] = cC; o[2] = cG; o[3] = cT; o[4] = probe;
+    }
 }
 
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
-                         const u8* traw, const u8* qraw, u32* counts, hipStream_t s)
+                         const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s)
 {
     if (launch_for == 0) return 0;
     const u64 threads = (u64)launch_for * 64;
     c.timer.begin("k_hsp_match_counts", s);
     hipLaunchKernelGGL(k_hsp_match_counts, dim3((unsigned)((threads + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, s,
-                       recs, n_rec_dev, cap, traw, qraw, counts);
+                       recs, n_rec_dev, cap, traw, qraw, tcode, qcode, c.seed, counts);
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
