@@ -376,11 +376,18 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
 
     g_hp.lap(7, "query slot");
     // ---- scoring classes, codes
-    u8 rowc[256], colc[256], cls[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
-    if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
-    if ((rc = c.score_tab.ensure(sizeof(tab)))) return rc;
-    LZ_HIP(hipMemcpyAsync(c.score_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
+    // (the class compression and the 4 KiB table upload are skipped when the caller passes the same
+    // matrix as last time -- lastz passes maskedScoring for every strand of every query)
+    static std::vector<s32> last_sub; static u8 rowc[256], colc[256]; static s32 tab[LZ_NCLASS * LZ_NCLASS];
+    u8 cls[256];
+    if (last_sub.size() != 65536 || memcmp(last_sub.data(), a->sub, 65536 * sizeof(s32)) != 0 || !c.score_tab.p) {
+        last_sub.clear();
+        if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
+        if ((rc = c.score_tab.ensure(sizeof(tab)))) return rc;
+        LZ_HIP(hipMemcpyAsync(c.score_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipStreamSynchronize(c.stream));
+        last_sub.assign(a->sub, a->sub + 65536);
+    }
     g_hp.lap(8, "score classes + table upload");
     lzh_make_cls(rowc, c.geom.char_to_bits, cls);
     if ((rc = slot_encode(c, c.target, cls, g_cls_t))) return rc;
