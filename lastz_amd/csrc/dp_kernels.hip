@@ -17,36 +17,47 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
     LzDpLane regs;
     template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
 
-    // exclusive scan of the per-lane gap maps (Hillis-Steele over the wave's 64 lanes)
-    __device__ __forceinline__ s32 scan_gap(s32 x0)
+    // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: wave shuffles inside each wave, per-wave
+    // partials through LDS, then every lane folds in the partials of the waves below it.
+    __device__ __forceinline__ s32 scan_gap(LzDpShared& sh, s32 x0)
     {
-        const int lane = (int)threadIdx.x;
+        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         LzDpGap inc = { regs.A, regs.K, regs.cut };
 #pragma unroll
-        for (int d = 1; d < LZ_DP_LANES; d <<= 1) {
+        for (int d = 1; d < 64; d <<= 1) {
             LzDpGap lo;
             lo.A = __shfl_up(inc.A, d); lo.K = __shfl_up(inc.K, d); lo.cut = __shfl_up(inc.cut, d);
-            if (lane >= d) inc = lz_dp_gap_compose(lo, inc);
+            if (wl >= d) inc = lz_dp_gap_compose(lo, inc);
         }
-        LzDpGap ex;
+        LzDpGap ex;                                              // exclusive inside the wave (lanes wl > 0)
         ex.A = __shfl_up(inc.A, 1); ex.K = __shfl_up(inc.K, 1); ex.cut = __shfl_up(inc.cut, 1);
-        regs.i_in = (lane == 0) ? x0 : lz_dp_gap_apply(ex, x0);
-        LzDpGap all;
-        all.A = __shfl(inc.A, LZ_DP_LANES - 1); all.K = __shfl(inc.K, LZ_DP_LANES - 1); all.cut = __shfl(inc.cut, LZ_DP_LANES - 1);
-        return lz_dp_gap_apply(all, x0);
+        if (wl == 63) sh.wg[w] = inc;
+        __syncthreads();
+        s32 xin = x0;                                            // value entering this wave
+        for (int j = 0; j < w; j++) xin = lz_dp_gap_apply(sh.wg[j], xin);
+        regs.i_in = (wl == 0) ? xin : lz_dp_gap_apply(ex, xin);
+        s32 xend = x0;
+        for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
+        __syncthreads();
+        return xend;
     }
-    __device__ __forceinline__ void scan_cand(s32 b0)
+    __device__ __forceinline__ void scan_cand(LzDpShared& sh, s32 b0)
     {
-        const int lane = (int)threadIdx.x;
+        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         s32 inc = regs.cand;
 #pragma unroll
-        for (int d = 1; d < LZ_DP_LANES; d <<= 1) { s32 v = __shfl_up(inc, d); if (lane >= d && v > inc) inc = v; }
-        s32 ex = __shfl_up(inc, 1);
-        regs.run_in = (lane == 0) ? b0 : (ex > b0 ? ex : b0);
+        for (int d = 1; d < 64; d <<= 1) { s32 v = __shfl_up(inc, d); if (wl >= d && v > inc) inc = v; }
+        const s32 ex = __shfl_up(inc, 1);
+        if (wl == 63) sh.wc[w] = inc;
+        __syncthreads();
+        s32 pre = b0;
+        for (int j = 0; j < w; j++) if (sh.wc[j] > pre) pre = sh.wc[j];
+        regs.run_in = (wl == 0) ? pre : (ex > pre ? ex : pre);
+        __syncthreads();
     }
     __device__ __forceinline__ void reduce_row(LzDpShared& sh)
     {
-        const int lane = (int)threadIdx.x;
+        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
         const s32 lo = has ? (s32)__ffsll((long long)has) - 1 : 0, hi = has ? 63 - (s32)__clzll((long long)has) : 0;
         const u32 first = __shfl(regs.first, lo), last = __shfl(regs.last, hi);
@@ -55,7 +66,16 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         for (int d = 32; d > 0; d >>= 1) { s32 v = __shfl_xor(cmax, d); if (v > cmax) cmax = v; }
         const u64 att = __ballot(regs.cand == cmax);            // the LAST lane attaining the max owns the column
         const u32 ccol = __shfl(regs.cand_col, 63 - (s32)__clzll((long long)att));
-        if (lane == 0) { sh.r_first = has ? first : 0xFFFFFFFFu; sh.r_last = has ? last : 0xFFFFFFFFu; sh.r_cmax = cmax; sh.r_ccol = ccol; }
+        if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
+        __syncthreads();
+        if (lane == 0) {
+            u32 f = 0xFFFFFFFFu, l = 0xFFFFFFFFu, cc = 0; s32 cm = LZ_DP_NEGINF - (1 << 24);
+            for (int j = 0; j < LZ_DP_WAVES; j++) {
+                if (sh.whas[j]) { if (f == 0xFFFFFFFFu) f = sh.wfirst[j]; l = sh.wlast[j]; }
+                if (sh.wcmax[j] >= cm) { cm = sh.wcmax[j]; cc = sh.wccol[j]; }
+            }
+            sh.r_first = f; sh.r_last = l; sh.r_cmax = cm; sh.r_ccol = cc;
+        }
         __syncthreads();
     }
 };

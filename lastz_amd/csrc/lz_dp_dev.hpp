@@ -25,9 +25,10 @@
 #pragma once
 #include "lz_common.hpp"
 
-#define LZ_DP_LANES   64
+#define LZ_DP_LANES   256             // lanes (threads) per one-sided DP: 4 waves of one workgroup
+#define LZ_DP_WAVES   (LZ_DP_LANES / 64)
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
-#define LZ_DP_BATCH   8               // cells whose LDS reads are issued together in the walks
+#define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ_UNROLL _Pragma("unroll")
 #else
@@ -76,6 +77,7 @@ struct LzDpParams {                     // per batch
     u8* tb_arena; u32* row_arena; u32* ops_arena;
 };
 
+struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
 struct LzDpActive { s32 align, seg; u32 x, last_row; s32 type; s32 filter; };
 
 struct LzDpShared {
@@ -84,7 +86,8 @@ struct LzDpShared {
     u8  lk[LZ_DP_MAXW];                   // traceback link of the current row
     u8  bb[LZ_DP_MAXW];                   // B (query) score classes of the band's columns, ring by column
     u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
-    // row results of the cross-lane reduction (written by lane 0)
+    // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
+    LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
     u32 r_first, r_last, r_ccol; s32 r_cmax;
     // sweep state (written by lane 0)
     s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter, ry_pro, sentinel;
@@ -107,12 +110,11 @@ struct LzDpLane {                       // per-lane values carried between the s
 };
 // Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
 // test harness); their semantics are fixed here:
-//   X::scan_gap(x0)   : r[l].i_in = (f_{l-1} o ... o f_0)(x0); returns (f_63 o ... o f_0)(x0)
+//   X::scan_gap(sh,x0): r[l].i_in = (f_{l-1} o ... o f_0)(x0); returns (f_63 o ... o f_0)(x0)
 //                       composition g o f: A = g.cut ? g.A : max(g.A, f.A - g.K), K = f.K + g.K, cut = f.cut | g.cut
-//   X::scan_cand(b0)  : r[l].run_in = max(b0, cand_0 .. cand_{l-1})
+//   X::scan_cand(sh,b0): r[l].run_in = max(b0, cand_0 .. cand_{l-1})
 //   X::reduce_row(..) : first live column (lowest lane having one), last live column (highest lane),
 //                       max cand and the column of the LAST lane attaining it
-struct LzDpGap { s32 A, K; u32 cut; };
 LZ_HD LzDpGap lz_dp_gap_compose(const LzDpGap& f, const LzDpGap& g)      // g after f
 {
     LzDpGap h;
@@ -319,7 +321,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         // row 0: C[0][0]=0, then insertions while the PREVIOUS column's C is >= -yDrop (note 13)
         u32 n0 = 1; s32 prevc = 0, c = -gapOE;
         while (n0 <= N && prevc >= -Y) { prevc = c; c -= gapE; n0++; }
-        if (n0 + 2 * LZ_DP_LANES + 8 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
+        if (n0 + LZ_DP_LANES + 72 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
         if (n0 > J.tb_cap || J.row_cap < 2) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; }
         sh.LY = 0; sh.RY = n0; sh.tb_used = n0; sh.cells = n0;
         if (!sh.done) trow[0] = 0;
@@ -359,7 +361,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             const s32 tb_needed = (s32)width + P.ydrop_tail;
             if ((s64)sh.tb_used + tb_needed >= (s64)P.tb_len) { sh.truncated = 1; sh.done = 1; sh.row--; return; }   // :3640-3661
             if ((u64)sh.tb_used + (u64)tb_needed > (u64)J.tb_cap) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; return; }
-            if (width + (u32)P.ydrop_tail + 2 * LZ_DP_LANES + 8 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
+            if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
             if (sh.row + 1 >= J.row_cap) { sh.status = LZ_DP_ROW_SLOT; sh.done = 1; return; }
             trow[sh.row] = sh.trow_cur = sh.tb_used - sh.LY;    // tbRow[row], :3662 (u32 wrap intended)
             sh.ry_iter = sh.RY;
@@ -410,7 +412,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
         {
-            const s32 i_end = x.scan_gap(LZ_DP_NEGINF);
+            const s32 i_end = x.scan_gap(sh, LZ_DP_NEGINF);
             x.phase([&](int lane, LzDpLane&) { if (lane == 0) sh.i_last = i_end; });
         }
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
@@ -459,7 +461,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.cand = cmax; r.cand_col = ccol;
         });
         // 64-lane exclusive prefix max of the candidates, seeded with bestScore at row start
-        x.scan_cand(best0);
+        x.scan_cand(sh, best0);
         // walk 3: prune test against the running best, final stores, traceback bytes
         x.phase([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;

@@ -12,12 +12,12 @@
 struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda for lanes 0..63
     LzDpLane lanes[LZ_DP_LANES];
     template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
-    s32 scan_gap(s32 x0) {
+    s32 scan_gap(LzDpShared&, s32 x0) {
         s32 x = x0;
         for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].i_in = x; LzDpGap f = { lanes[l].A, lanes[l].K, lanes[l].cut }; x = lz_dp_gap_apply(f, x); }
         return x;
     }
-    void scan_cand(s32 b0) { s32 rb = b0; for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].run_in = rb; if (lanes[l].cand > rb) rb = lanes[l].cand; } }
+    void scan_cand(LzDpShared&, s32 b0) { s32 rb = b0; for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].run_in = rb; if (lanes[l].cand > rb) rb = lanes[l].cand; } }
     void reduce_row(LzDpShared& sh) {
         u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu, ccol = 0; s32 cmax = LZ_DP_NEGINF - (1 << 24);
         for (int l = 0; l < LZ_DP_LANES; l++) {
