@@ -28,6 +28,7 @@
 #define LZ_DP_LANES   256             // lanes (threads) per one-sided DP: 4 waves of one workgroup
 #define LZ_DP_WAVES   (LZ_DP_LANES / 64)
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
+#define LZ_DP_TBWIN   64              // traceback look-ahead window (links along one diagonal)
 #define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ_UNROLL _Pragma("unroll")
@@ -99,6 +100,9 @@ struct LzDpShared {
     u32 b_hi, trow_cur;                   // columns < b_hi are staged in bb[]; tbRow[row] of the current row
     u32 max_row, min_col, max_col; u64 cells;
     LzDpSeg lcur, rcur;                   // copies of segs[left_seg] / segs[right_seg]
+    // traceback state
+    u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
+    u8  tb_win[64];
     LzDpActive act[LZ_DP_MAXACT];
 };
 
@@ -270,13 +274,6 @@ LZ_HD void lz_dp_update_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDp
     u32 w = 0;                                                 // filter_active_segs(&active, 0)
     for (u32 k = 0; k < sh.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
     sh.n_act = w;
-}
-
-LZ_HD void lz_dp_ops_add(u32* ops, u32& n, u32 cap, u32& status, u32 op)
-{   // edit_script_add(script, op, 1), src/edit_script.c:261-300 (repeat counts never reach 2^30 here)
-    if (n > 0 && (ops[n - 1] & 3u) == op) { ops[n - 1] += 4u; return; }
-    if (n >= cap) { status = LZ_DP_OPS_SLOT; return; }
-    ops[n++] = op | 4u;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -543,31 +540,60 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
     }
 
-    // ---- traceback (:3847-3859) and result (lane 0)
+    // ---- traceback (:3847-3859).  The walk is one dependent byte per step; to keep it off HBM latency
+    // the first 64 lanes fetch the links along the diagonal below the current point (the path of an
+    // alignment is a diagonal between gaps), lane 0 then consumes the window from LDS for as long as the
+    // path stays on that diagonal and asks for a new window after a gap.  Edit ops are run-length merged
+    // in registers (edit_script_add, src/edit_script.c:261-300) and stored once per run.
+    const u64 t1 = LZ_CLOCK();
     x.phase([&](int lane, LzDpLane&) {
         if (lane != 0) return;
-        const u64 t1 = LZ_CLOCK();
-        u32 n_ops = 0, status = sh.status;
-        if (status == LZ_DP_OK) {
-            u32 row = sh.end1, col = sh.end2; u32 prev_op = 0, op;
-            u32 tr_cur = trow[row], tr_prev = row ? trow[row - 1] : 0;
-            while (row >= 1 || col > 0) {
-                const u32 link = tb[(u32)(tr_cur + col)];
-                op = link & 3u;
+        sh.tb_row = sh.end1; sh.tb_col = sh.end2; sh.tb_prev = 0; sh.tb_nops = 0; sh.tb_run_op = 0; sh.tb_run_len = 0;
+        sh.tb_done = (sh.status != LZ_DP_OK) || !(sh.end1 >= 1 || sh.end2 > 0);
+    });
+    while (!sh.tb_done) {
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane >= LZ_DP_TBWIN) return;
+            const u32 k = (u32)lane;
+            u32 v = 0xFFu;
+            if (k <= sh.tb_row && k <= sh.tb_col) v = tb[(u32)(trow[sh.tb_row - k] + (sh.tb_col - k))];
+            sh.tb_win[k] = (u8)v;
+        });
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != 0) return;
+            u32 row = sh.tb_row, col = sh.tb_col, prev_op = sh.tb_prev, n_ops = sh.tb_nops;
+            u32 run_op = sh.tb_run_op, run_len = sh.tb_run_len, status = sh.status;
+            for (u32 k = 0; k < LZ_DP_TBWIN; k++) {
+                if (!(row >= 1 || col > 0)) break;
+                const u32 link = sh.tb_win[k];
+                u32 op = link & 3u;
                 if (prev_op == LZ_C_FROM_I && (link & LZ_I_EXT)) op = LZ_C_FROM_I;
                 if (prev_op == LZ_C_FROM_D && (link & LZ_D_EXT)) op = LZ_C_FROM_D;
-                if (op == LZ_C_FROM_I)      { col--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 1u); }
+                const u32 eop = (op == LZ_C_FROM_I) ? 1u : (op == LZ_C_FROM_D) ? 2u : 3u;
+                if (eop == run_op) run_len++;
                 else {
-                    if (op == LZ_C_FROM_D)  { row--;        lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 2u); }
-                    else                    { row--; col--; lz_dp_ops_add(ops, n_ops, J.ops_cap, status, 3u); }
-                    tr_cur = tr_prev; tr_prev = row ? trow[row - 1] : 0;      // one row ahead of the dependent byte load
+                    if (run_len) { if (n_ops >= J.ops_cap) { status = LZ_DP_OPS_SLOT; break; } ops[n_ops++] = run_op | (run_len << 2); }
+                    run_op = eop; run_len = 1;
                 }
-                if (status != LZ_DP_OK) break;
                 prev_op = op;
+                if (op == LZ_C_FROM_I)      { col--; }
+                else if (op == LZ_C_FROM_D) { row--; }
+                else                        { row--; col--; continue; }       // still on the window's diagonal
+                break;                                                          // a gap: the window is stale
             }
-        }
-        res->score = sh.best; res->end1 = sh.end1; res->end2 = sh.end2; res->n_ops = n_ops;
-        res->status = status; res->truncated = sh.truncated;
+            const bool fin = (status != LZ_DP_OK) || !(row >= 1 || col > 0);
+            if (fin && status == LZ_DP_OK && run_len) {
+                if (n_ops >= J.ops_cap) status = LZ_DP_OPS_SLOT; else ops[n_ops++] = run_op | (run_len << 2);
+                run_len = 0;
+            }
+            sh.tb_row = row; sh.tb_col = col; sh.tb_prev = prev_op; sh.tb_nops = n_ops;
+            sh.tb_run_op = run_op; sh.tb_run_len = run_len; sh.status = status; sh.tb_done = fin;
+        });
+    }
+    x.phase([&](int lane, LzDpLane&) {
+        if (lane != 0) return;
+        res->score = sh.best; res->end1 = sh.end1; res->end2 = sh.end2; res->n_ops = sh.tb_nops;
+        res->status = sh.status; res->truncated = sh.truncated;
         res->max_row = sh.max_row; res->min_col = sh.min_col; res->max_col = sh.max_col;
         res->tb_used = sh.tb_used; res->cells = sh.cells;
         res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
