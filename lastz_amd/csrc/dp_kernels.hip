@@ -16,6 +16,7 @@
 struct GpuPhases {                      // X for lz_dp_run: one thread = one lane, barrier after each phase
     LzDpLane regs;
     template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
+    template <class F> __device__ __forceinline__ void step(F&& f)  { f((int)threadIdx.x, regs); }
 
     // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: wave shuffles inside each wave, per-wave
     // partials through LDS, then every lane folds in the partials of the waves below it.
@@ -38,8 +39,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         regs.i_in = (wl == 0) ? xin : lz_dp_gap_apply(ex, xin);
         s32 xend = x0;
         for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
-        __syncthreads();
-        return xend;
+        return xend;                                            // (wg[] is rewritten a row later, barriers in between)
     }
     __device__ __forceinline__ void scan_cand(LzDpShared& sh, s32 b0)
     {
@@ -53,7 +53,6 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         s32 pre = b0;
         for (int j = 0; j < w; j++) if (sh.wc[j] > pre) pre = sh.wc[j];
         regs.run_in = (wl == 0) ? pre : (ex > pre ? ex : pre);
-        __syncthreads();
     }
     __device__ __forceinline__ void reduce_row(LzDpShared& sh)
     {
@@ -68,15 +67,16 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         const u32 ccol = __shfl(regs.cand_col, 63 - (s32)__clzll((long long)att));
         if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
         __syncthreads();
-        if (lane == 0) {
-            u32 f = 0xFFFFFFFFu, l = 0xFFFFFFFFu, cc = 0; s32 cm = LZ_DP_NEGINF - (1 << 24);
-            for (int j = 0; j < LZ_DP_WAVES; j++) {
-                if (sh.whas[j]) { if (f == 0xFFFFFFFFu) f = sh.wfirst[j]; l = sh.wlast[j]; }
-                if (sh.wcmax[j] >= cm) { cm = sh.wcmax[j]; cc = sh.wccol[j]; }
-            }
-            sh.r_first = f; sh.r_last = l; sh.r_cmax = cm; sh.r_ccol = cc;
+    }
+    __device__ __forceinline__ void row_result(const LzDpShared& sh, u32& first, u32& last, s32& cmax, u32& ccol)   // lane 0
+    {
+        u32 f = 0xFFFFFFFFu, l = 0xFFFFFFFFu, cc = 0; s32 cm = LZ_DP_NEGINF - (1 << 24);
+#pragma unroll
+        for (int j = 0; j < LZ_DP_WAVES; j++) {
+            if (sh.whas[j]) { if (f == 0xFFFFFFFFu) f = sh.wfirst[j]; l = sh.wlast[j]; }
+            if (sh.wcmax[j] >= cm) { cm = sh.wcmax[j]; cc = sh.wccol[j]; }
         }
-        __syncthreads();
+        first = f; last = l; cmax = cm; ccol = cc;
     }
 };
 
@@ -90,7 +90,8 @@ k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u3
     __syncthreads();
     const u32 j = job_ids[blockIdx.x];
     GpuPhases x;
-    lz_dp_run(x, sh, S, P, jobs[j], tab, &res[j]);
+    const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
+    lz_dp_run(x, sh, S, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -151,12 +152,13 @@ struct HipDpExec : LzDpExecutor {
         c.timer.resolve();
         for (u32 id : ids) res[id] = all[id];
         if (getenv("LZGPU_DPPROF")) {
-            u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0;
+            u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0; u64 ph[4] = { 0, 0, 0, 0 };
             for (u32 id : ids) { sum_r += all[id].t_rows; sum_t += all[id].t_trace;
-                                 if (all[id].t_rows + all[id].t_trace > mr) { mr = all[id].t_rows + all[id].t_trace; tr = all[id].t_rows; tt = all[id].t_trace; rows = all[id].max_row; cells = all[id].cells; } }
-            fprintf(stderr, "[lzgpu dpprof] launch of %zu DPs: longest = %u rows, %llu cells, sweep %llu ticks (%.0f/row), traceback %llu ticks; all DPs: sweep %llu, traceback %llu ticks\n",
+                                 if (all[id].t_rows + all[id].t_trace > mr) { for (int q = 0; q < 4; q++) ph[q] = all[id].t_ph[q]; mr = all[id].t_rows + all[id].t_trace; tr = all[id].t_rows; tt = all[id].t_trace; rows = all[id].max_row; cells = all[id].cells; } }
+            fprintf(stderr, "[lzgpu dpprof] launch of %zu DPs: longest = %u rows, %llu cells, sweep %llu ticks (%.0f/row), traceback %llu ticks; all DPs: sweep %llu, traceback %llu ticks; longest by step: lane0 %llu, walk1+scan %llu, walk2+scan %llu, walk3+reduce %llu\n",
                     ids.size(), rows, (unsigned long long)cells, (unsigned long long)tr, rows ? (double)tr / rows : 0.0, (unsigned long long)tt,
-                    (unsigned long long)sum_r, (unsigned long long)sum_t);
+                    (unsigned long long)sum_r, (unsigned long long)sum_t,
+                    (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3]);
         }
         return 0;
     }

@@ -215,9 +215,8 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
     for (;;) {
         if (!in_hit) {
             // Settle hits straight from their phase-A summaries for as long as that is possible
-            // (97 % of the hits of a random-sequence background); the loads of a group of four
-            // (key, summary) pairs are issued together.  Stop at the first hit that needs the
-            // sequences (flagged SLOW by phase A, or its left scan is clipped by diagEnd).
+            // (all but the hits phase A flagged SLOW: possible HSPs and scans that ran into the cap);
+            // the loads of a group of four (key, summary) pairs are issued together.
             bool start = false;
             for (int budget = LZ_FAST_RUN; budget > 0 && i < i1 && !start; budget--) {
                 u64 k4[4]; u32 s4[4];
@@ -230,10 +229,15 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
                     if (dend > p2 - L) continue;                    // :1113
                     n_ext++;
                     const u32 sm = s4[u];
-                    if (!(sm & LZ_SUMM_SLOW) && dend <= p2 - LZ_SUMM_DLO(sm)) {
+                    if (!(sm & LZ_SUMM_SLOW)) {
+                        // The unclipped scans scored below the threshold.  A left scan clipped at
+                        // diagEnd walks a prefix of the same bases (its best can only be lower: still
+                        // no HSP) and the right scan does not depend on it: only the count of bases
+                        // differs, min(unclipped, room).
+                        const u32 room = p2 - dend, dlo = LZ_SUMM_DLO(sm);
                         const u32 extent = p2 + LZ_SUMM_DEXT(sm);   // :2785
+                        n_bp += (dlo < room ? dlo : room) + LZ_SUMM_DEXT(sm);   // :2818
                         if (extent > dend) dend = extent;
-                        n_bp += LZ_SUMM_DLO(sm) + LZ_SUMM_DEXT(sm); // :2818
                         continue;
                     }
                     pos2 = p2;

@@ -35,6 +35,7 @@
 #else
 #define LZ_UNROLL
 #endif
+#define LZ_DP_SERIAL_FILL 4           // overhang cells lane 0 stores itself at row end
 #define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
@@ -68,6 +69,7 @@ struct LzDpResult {
     u32 max_row, min_col, max_col;      // explored region in DP coordinates (row 0..max_row)
     u32 tb_used; u64 cells;
     u64 t_rows, t_trace;                // shader-clock ticks spent in the row sweep / the traceback (0 off-device)
+    u64 t_ph[4];                        // ... of which: lane-0 step, walk 1 + gap scan, walk 2 + best scan, walk 3 + reduce
 };
 
 struct LzDpParams {                     // per batch
@@ -91,11 +93,11 @@ struct LzDpShared {
     LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
     u32 r_first, r_last, r_ccol; s32 r_cmax;
     // sweep state (written by lane 0)
-    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter, ry_pro, sentinel;
+    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter;
     s32 best; u32 end1, end2;
     s32 left_align, right_align, left_seg, right_seg, list_pos;
-    u32 tb_used, n_act, done, status, truncated, n_prolong;
-    s32 i_last;
+    u32 tb_used, n_act, done, status, truncated;
+    u32 extra, fill_n, fill_base, fill_trow, stage_lo, stage_a; s32 fill_i;   // work for all lanes before the next row
     u32 next_act_row;                     // row at which aligns[order[list_pos]] becomes active
     u32 b_hi, trow_cur;                   // columns < b_hi are staged in bb[]; tbRow[row] of the current row
     u32 max_row, min_col, max_col; u64 cells;
@@ -118,7 +120,10 @@ struct LzDpLane {                       // per-lane values carried between the s
 //                       composition g o f: A = g.cut ? g.A : max(g.A, f.A - g.K), K = f.K + g.K, cut = f.cut | g.cut
 //   X::scan_cand(sh,b0): r[l].run_in = max(b0, cand_0 .. cand_{l-1})
 //   X::reduce_row(..) : first live column (lowest lane having one), last live column (highest lane),
-//                       max cand and the column of the LAST lane attaining it
+//                       max cand and the column of the LAST lane attaining it; lane 0 fetches them in
+//                       its next phase with X::row_result
+//   X::phase(f) runs f on every lane and ends with a barrier; X::step(f) has no barrier: f may touch
+//   only registers and the LDS cells of its own columns, and is followed by a cross-lane step.
 LZ_HD LzDpGap lz_dp_gap_compose(const LzDpGap& f, const LzDpGap& g)      // g after f
 {
     LzDpGap h;
@@ -290,7 +295,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
             if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
-                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; } });
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; res->t_ph[0] = res->t_ph[1] = res->t_ph[2] = res->t_ph[3] = 0; } });
         return;
     }
 
@@ -341,13 +346,62 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
     }
 
-    // ---- rows 1..M (:3607-3828)
+    // ---- rows 1..M (:3607-3828).  One iteration = the row-end step of the row the previous iteration
+    // swept, fused with the set-up of the next row (both are lane-0 work: one barrier instead of three),
+    // then the three walks, separated only by the barrier inside each cross-lane step.
+    u32 row = 0, LY0 = 0, RYi = 0, cpl = 0, trow_cur = 0; s32 best0 = 0, i_last = 0;     // of the row in flight (uniform)
+    bool swept = false;
+    u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
     while (!sh.done) {
-        // phase 0 (lane 0): bounds, active segments, traceback budget
+        const u64 ts = LZ_CLOCK();
         x.phase([&](int lane, LzDpLane&) {
             if (lane != 0) return;
+            u32 extra = 0;
+            if (swept) {
+                // row end: new LY, best/end, right bound, overhang (:3769-3827)
+                u32 first, last, ccol; s32 cmax;
+                x.row_result(sh, first, last, cmax, ccol);
+                const u32 iter = RYi - LY0;
+                sh.cells += iter;
+                u32 tb_used = sh.tb_used + iter;
+                s32 best = best0;
+                if (cmax >= best0) { best = cmax; sh.best = cmax; sh.end1 = row; sh.end2 = ccol; }      // :3731-3735
+                if (first == 0xFFFFFFFFu) { sh.tb_used = tb_used; sh.LY = RYi; sh.done = 1; return; }   // LY >= RY: feasible region empty
+                sh.LY = first;
+                if (LY0 < sh.min_col) sh.min_col = LY0;
+                sh.max_row = row;
+                const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
+                u32 RY = RYi, np = 0;
+                if (RY > last + 1) RY = last + 1;
+                else {
+                    const s32 thr = best - Y; s32 i = i_last;
+                    while (i >= thr && (s32)RY <= NN) { np++; RY++; i -= gapE; }
+                }
+                // overhang cells C=i, D=i-gapOE, link=I (:3799-3811): a few are stored here, a long run by all lanes
+                if (np <= LZ_DP_SERIAL_FILL) {
+                    const u32 base = RY - np;
+                    for (u32 k = 0; k < np; k++) {
+                        const s32 iv = i_last - (s32)k * gapE;
+                        sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
+                        tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
+                    }
+                    sh.fill_n = 0;
+                } else { sh.fill_n = np; sh.fill_base = RY - np; sh.fill_i = i_last; sh.fill_trow = trow_cur; extra = 1; }
+                tb_used += np;
+                if (RY - 1 > sh.max_col) sh.max_col = RY - 1;
+                if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; RY++; }   // terminating cell, :3818-3826
+                sh.RY = RY; sh.tb_used = tb_used;
+                // B classes of the columns the next row may reach; every LZ_DP_LANES rows the next block of A classes
+                u32 bh = sh.b_hi;
+                sh.stage_lo = bh;
+                while (RY + 2 > bh) { bh += LZ_DP_LANES; extra = 1; }
+                sh.b_hi = bh;
+                sh.stage_a = ((row & (LZ_DP_LANES - 1)) == 0) ? row + 1 : 0;
+                if (sh.stage_a) extra = 1;
+            }
+            sh.extra = extra;
+            // set-up of the next row: bounds, active segments, traceback budget
             if (sh.row >= M) { sh.done = 1; return; }
-            while (sh.RY + 2 > sh.b_hi) sh.b_hi += LZ_DP_LANES;     // staged by the previous row's last phase
             sh.row++;
             sh.prevLY = sh.LY;
             lz_dp_update_lr(S, sh, J);
@@ -365,18 +419,32 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
         });
         if (sh.done) break;
-        const u32 row = sh.row, LY0 = sh.LY, RYi = sh.ry_iter, cpl = sh.cpl;
-        const s32 best0 = sh.best;
+        if (sh.extra) x.phase([&](int lane, LzDpLane&) {
+            const u32 np = sh.fill_n, base = sh.fill_base;
+            for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
+                const s32 iv = sh.fill_i - (s32)k * gapE;
+                sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
+                tb[(u32)(sh.fill_trow + base + k)] = LZ_C_FROM_I;
+            }
+            for (u32 col = sh.stage_lo + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES)
+                sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
+            if (sh.stage_a) {
+                const u32 r2 = sh.stage_a + (u32)lane;
+                sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
+            }
+        });
+        row = sh.row; LY0 = sh.LY; RYi = sh.ry_iter; cpl = sh.cpl; best0 = sh.best; trow_cur = sh.trow_cur;
+        swept = true;
         const bool any_active = sh.n_act != 0;
         const u32 arow = sh.aa[(row - 1) & (LZ_DP_LANES - 1)];
-        const u32 trow_cur = sh.trow_cur;
         const s32* trow_tab = tab + (arow << 5);
 
         // The walks read the sweep row in batches of LZ_DP_BATCH cells: all LDS reads of a batch are
         // issued before the serial recurrence consumes them (one wave per SIMD has nothing else to
         // hide LDS latency behind).
         // walk 1: block summaries of the insertion recurrence
-        x.phase([&](int lane, LzDpLane& r) {
+        const u64 ta = LZ_CLOCK();
+        x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
             r.c_left_old = (c0 < RYi && c0 > LY0) ? sh.cc[LZ_RING(c0 - 1)] : LZ_DP_NEGINF;
@@ -408,12 +476,10 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.A = A; r.K = K; r.cut = cut;
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
-        {
-            const s32 i_end = x.scan_gap(sh, LZ_DP_NEGINF);
-            x.phase([&](int lane, LzDpLane&) { if (lane == 0) sh.i_last = i_end; });
-        }
+        i_last = x.scan_gap(sh, LZ_DP_NEGINF);
+        const u64 tb_ = LZ_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
-        x.phase([&](int lane, LzDpLane& r) {
+        x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
@@ -459,8 +525,9 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
         // 64-lane exclusive prefix max of the candidates, seeded with bestScore at row start
         x.scan_cand(sh, best0);
+        const u64 tc = LZ_CLOCK();
         // walk 3: prune test against the running best, final stores, traceback bytes
-        x.phase([&](int lane, LzDpLane& r) {
+        x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
@@ -490,54 +557,8 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.first = first; r.last = last;
         });
         x.reduce_row(sh);
-        // row end (lane 0): new LY, best/end, right bound, overhang (:3769-3827)
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane != 0) return;
-            const u32 first = sh.r_first, last = sh.r_last, ccol = sh.r_ccol; const s32 cmax = sh.r_cmax;
-            const u32 iter = RYi - LY0;
-            sh.cells += iter;
-            sh.tb_used += iter;
-            if (cmax >= best0) { sh.best = cmax; sh.end1 = row; sh.end2 = ccol; }       // :3731-3735
-            if (first == 0xFFFFFFFFu) { sh.LY = RYi; sh.done = 1; sh.n_prolong = 0; return; }   // LY >= RY: feasible region empty
-            sh.LY = first;
-            if (LY0 < sh.min_col) sh.min_col = LY0;
-            sh.max_row = row;
-            const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
-            u32 RY = RYi, np = 0;
-            s32 i = sh.i_last;
-            if (RY > last + 1) RY = last + 1;
-            else {
-                const s32 thr = sh.best - Y;
-                while (i >= thr && (s32)RY <= NN) { np++; RY++; i -= gapE; }            // counted here, stored in the next phase
-            }
-            sh.n_prolong = np;
-            sh.tb_used += np;
-            sh.ry_pro = RY;                                         // right bound before the terminating cell
-            sh.sentinel = ((s32)RY <= NN) ? 1u : 0u;                // :3818-3826
-            sh.RY = RY + sh.sentinel;
-            if (RY - 1 > sh.max_col) sh.max_col = RY - 1;
-        });
-        if (sh.done) break;
-        // overhang cells C=i, D=i-gapOE, link=I (:3799-3811) and the terminating -inf cell (:3818-3826)
-        x.phase([&](int lane, LzDpLane&) {
-            const u32 np = sh.n_prolong, RY = sh.ry_pro, base = RY - np;
-            for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
-                const s32 iv = sh.i_last - (s32)k * gapE;
-                sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
-                tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
-            }
-            if (lane == 0 && sh.sentinel) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; }
-            // stage the B classes of the columns the next row may reach, and every 64 rows the next
-            // block of A classes (coalesced loads; the walks then touch LDS only)
-            for (u32 bh = sh.b_hi; sh.RY + 2 > bh; bh += LZ_DP_LANES) {
-                const u32 col = bh + (u32)lane;
-                sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
-            }
-            if ((row & (LZ_DP_LANES - 1)) == 0) {
-                const u32 r2 = row + 1 + (u32)lane;
-                sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
-            }
-        });
+        const u64 td = LZ_CLOCK();
+        tp0 += ta - ts; tp1 += tb_ - ta; tp2 += tc - tb_; tp3 += td - tc;
     }
 
     // ---- traceback (:3847-3859).  The walk is one dependent byte per step; to keep it off HBM latency
@@ -597,5 +618,6 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         res->max_row = sh.max_row; res->min_col = sh.min_col; res->max_col = sh.max_col;
         res->tb_used = sh.tb_used; res->cells = sh.cells;
         res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
+        res->t_ph[0] = tp0; res->t_ph[1] = tp1; res->t_ph[2] = tp2; res->t_ph[3] = tp3;
     });
 }

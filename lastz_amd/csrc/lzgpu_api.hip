@@ -471,6 +471,10 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     LZ_HIP(hipEventRecord(c.ev_init, c.stream));              // state resets above are on stream 1
     LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_init, 0));
     size_t ci = 0;
+    // LZGPU_SERIAL=1 (profiling aid): phase B on stream 1 too, so that per-kernel event times are not
+    // inflated by the other stream's kernels sharing the CUs
+    static const bool serial = getenv("LZGPU_SERIAL") != nullptr;
+    hipStream_t sB = serial ? c.stream : c.stream2;
     for (auto& ch : chunks) {
         if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.pk.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
@@ -491,11 +495,11 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
         if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), kb, c.summ_a.as<u32>(), sb, ch.nh))) return rc;
         LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
-        LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_sorted[set], 0));
-        if ((rc = lzk_bucket_bounds(c, kb, ch.nh, bs, c.stream2))) return rc;
+        LZ_HIP(hipStreamWaitEvent(sB, c.ev_sorted[set], 0));
+        if ((rc = lzk_bucket_bounds(c, kb, ch.nh, bs, sB))) return rc;
         if ((rc = lzk_extend(c, P, kb, sb, bs, c.diag_end.as<u32>(), c.score_tab.as<s32>(),
-                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, c.stream2))) return rc;
-        LZ_HIP(hipEventRecord(c.ev_extended[set], c.stream2));
+                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, sB))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_extended[set], sB));
         ci++;
     }
     g_hp.lap(3, "chunk loop launches");

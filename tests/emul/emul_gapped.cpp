@@ -12,6 +12,8 @@
 struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda for lanes 0..63
     LzDpLane lanes[LZ_DP_LANES];
     template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
+    template <class F> void step(F&& f)  { for (int l = LZ_DP_LANES - 1; l >= 0; l--) f(l, lanes[l]); }   // no barrier on the GPU: any lane order must do
+    void row_result(const LzDpShared& sh, u32& first, u32& last, s32& cmax, u32& ccol) { first = sh.r_first; last = sh.r_last; cmax = sh.r_cmax; ccol = sh.r_ccol; }
     s32 scan_gap(LzDpShared&, s32 x0) {
         s32 x = x0;
         for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].i_in = x; LzDpGap f = { lanes[l].A, lanes[l].K, lanes[l].cut }; x = lz_dp_gap_apply(f, x); }
