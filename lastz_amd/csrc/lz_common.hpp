@@ -108,6 +108,7 @@ struct LzExtendParams {
     s32 xdrop;
     s32 min_score;                 // candidates with left+right >= min_score are emitted
     u32 seed_len;
+    u32 cls8;                      // every scoring class of either sequence is < 8: lz_scan16_fast is usable
 };
 
 struct LzVec16 { u32 w[4]; };
@@ -126,11 +127,115 @@ LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); r
 // record is needed) is flagged SLOW and re-done in order by phase B.
 #define LZ_PROBE_CAP   128            // multiple of 16
 #define LZ_SUMM_SLOW   0x10000u
-#define LZ_FAST_RUN    8              // groups of 4 hits settled per trip of the phase-B loop
+#define LZ_FAST_GROUP  16             // (key, summary) pairs loaded together: phase B runs one wave per SIMD, so
+                                     // the bytes in flight per lane are what hides the memory latency
+#define LZ_FAST_RUN    4              // groups settled per trip of the phase-B loop
 #define LZ_SUMM_DLO(s)  ((s) & 0xFFu)         // pos2 - lo   (bases the left scan consumed)
 #define LZ_SUMM_DEXT(s) (((s) >> 8) & 0xFFu)  // extent - pos2 (bases the right scan consumed)
 
-LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, u64 key)
+// A whole block in one go, for the common case (>= 16 bases of room, < 8 scoring classes).
+// - score look-up: (row class << 5 | column class << 2) IS the byte address in an 8 x 8 table,
+//   built four bases at a time; with 8 words per row the 16 ACGT pairs fall into 16 LDS banks.
+// - X-drop chain without masks: a base passes if run >= best - xDrop (the test of the reference
+//   with best not yet updated -- the same thing, as xDrop >= 0); the first base that fails is
+//   replaced by a poison value that makes every later base fail too and never raises best.
+// Returns the number of bases that passed (16: the scan goes on; otherwise the scan consumed one
+// more base, the failing one, and stopped).  run is meaningless after a failure.
+#define LZ_SCAN_POISON (-(1 << 30))
+template <bool REV>
+LZ_HD u32 lz_scan16_fast(const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv, s32& run, s32& best)
+{
+    u32 x[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; j++) x[j] = ((tv.w[j] & 0x07070707u) << 5) | ((qv.w[j] & 0x07070707u) << 2);
+    s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++) {
+        const int b = REV ? 15 - k : k;
+        sc[k] = *(const s32*)((const u8*)tab8 + ((x[b >> 2] >> ((b & 3) * 8)) & 0xFFu));
+    }
+    s32 p = run, thr = best - xd;
+    u32 nok = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++) {
+        p += sc[k];
+        const bool ok = p >= thr;
+        nok += ok ? 1u : 0u;
+        const s32 t = p - xd;
+        thr = t > thr ? t : thr;
+        p = ok ? p : LZ_SCAN_POISON;
+    }
+    run = p; best = thr + xd;
+    return nok;
+}
+
+// One 16-base block of the left scan (loop 1, :2623-2632: bases sl-1, sl-2, ... taken from the
+// 16 bytes that END at sl) and of the right scan (loop 2, :2684-2693: the 16 bytes that START at sr).
+// "run >= best - xDrop" gates each further base; the return value says whether the scan goes on.
+LZ_HD bool lz_scan_left16(const s32* score_tab, const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv,
+                          s32 stopl, u32& sl, s32& runl, s32& bestl)
+{
+    const u32 room = (u32)((s32)sl - stopl);
+    if (tab8 && room >= 16u && xd >= 0) {
+        const u32 nok = lz_scan16_fast<true>(tab8, xd, tv, qv, runl, bestl);
+        sl -= (nok < 16u) ? nok + 1u : 16u;
+        return nok == 16u && (s32)sl > stopl;
+    }
+    s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++)
+        sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, 15 - k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, 15 - k))];
+    bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++)
+        if (go && (u32)k < room) { runl += sc[k]; --sl; if (runl > bestl) bestl = runl; go = runl >= bestl - xd; }
+    return go && ((s32)sl > stopl);
+}
+LZ_HD bool lz_scan_right16(const s32* score_tab, const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv,
+                           s32 stopr, u32& sr, s32& runr, s32& bestr)
+{
+    const u32 room = (u32)(stopr - (s32)sr);
+    if (tab8 && room >= 16u && xd >= 0) {
+        const u32 nok = lz_scan16_fast<false>(tab8, xd, tv, qv, runr, bestr);
+        sr += (nok < 16u) ? nok + 1u : 16u;
+        return nok == 16u && (s32)sr < stopr;
+    }
+    s32 sc[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++)
+        sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, k))];
+    bool go = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++)
+        if (go && (u32)k < room) { runr += sc[k]; ++sr; if (runr > bestr) bestr = runr; go = runr >= bestr - xd; }
+    return go && ((s32)sr < stopr);
+}
+
+// Phase A of one hit.  The scans are memory-latency bound (a random target line per hit), and the
+// address of every block is known from the key alone: the first LZ_PROBE_AHEAD_L / _R blocks of
+// both sequences are loaded before any of them is scored, so a hit costs two dependent memory round
+// trips (key, blocks) instead of one per block; the few scans that are still going after that
+// continue block by block.  (The 64 bytes of padding around the sequences cover the blocks that
+// reach over either end.)
+#ifndef LZ_PROBE_AHEAD_L
+#define LZ_PROBE_AHEAD_L 2
+#define LZ_PROBE_AHEAD_R 1
+#endif
+LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key)
 {
     const s32 xd = P.xdrop;
     const u32 pos2 = (u32)key;
@@ -138,47 +243,33 @@ LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, u64 key)
     const u32 pos1 = pos2 + (u32)diag;
     const s32 stopl = diag > 0 ? diag : 0;                                               // diagEnd == 0
     const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
+    const u8* tp = P.tcode + pos1;
+    const u8* qp = P.qcode + pos2;
+    LzVec16 tl[LZ_PROBE_AHEAD_L], ql[LZ_PROBE_AHEAD_L], tr[LZ_PROBE_AHEAD_R], qr[LZ_PROBE_AHEAD_R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; b < LZ_PROBE_AHEAD_L; b++) { tl[b] = lz_load16(tp - 16 * (b + 1)); ql[b] = lz_load16(qp - 16 * (b + 1)); }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; b < LZ_PROBE_AHEAD_R; b++) { tr[b] = lz_load16(tp + 16 * b); qr[b] = lz_load16(qp + 16 * b); }
     u32 sl = pos1, sr = pos1;
     s32 runl = 0, bestl = 0, runr = 0, bestr = 0;
     bool alive_l = ((s32)sl > stopl) && (0 >= -xd);
     bool alive_r = ((s32)sr < stopr) && (0 >= -xd);
-    for (int blk = 0; blk < LZ_PROBE_CAP / 16 && (alive_l || alive_r); blk++) {
-        if (alive_l) {
-            const u32 room = (u32)((s32)sl - stopl);
-            const LzVec16 tv = lz_load16(P.tcode + sl - 16);
-            const LzVec16 qv = lz_load16(P.qcode + ((s32)sl - diag) - 16);
-            s32 sc[16];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-            for (int k = 0; k < 16; k++)
-                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, 15 - k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, 15 - k))];
-            bool go = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < 16; k++)
-                if (go && (u32)k < room) { runl += sc[k]; --sl; if (runl > bestl) bestl = runl; go = runl >= bestl - xd; }
-            alive_l = go && ((s32)sl > stopl);
-        }
-        if (alive_r) {
-            const u32 room = (u32)(stopr - (s32)sr);
-            const LzVec16 tv = lz_load16(P.tcode + sr);
-            const LzVec16 qv = lz_load16(P.qcode + ((s32)sr - diag));
-            s32 sc[16];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < 16; k++)
-                sc[k] = score_tab[(LZ_CODE_CLASS(LZ_VBYTE(tv, k)) << 5) | LZ_CODE_CLASS(LZ_VBYTE(qv, k))];
-            bool go = true;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < 16; k++)
-                if (go && (u32)k < room) { runr += sc[k]; ++sr; if (runr > bestr) bestr = runr; go = runr >= bestr - xd; }
-            alive_r = go && ((s32)sr < stopr);
-        }
+    for (int b = 0; b < LZ_PROBE_AHEAD_L; b++) {
+        if (alive_l) alive_l = lz_scan_left16(score_tab, tab8, xd, tl[b], ql[b], stopl, sl, runl, bestl);
+        if (b < LZ_PROBE_AHEAD_R && alive_r) alive_r = lz_scan_right16(score_tab, tab8, xd, tr[b], qr[b], stopr, sr, runr, bestr);
+    }
+    for (int blk = LZ_PROBE_AHEAD_R; blk < LZ_PROBE_CAP / 16 && (alive_l || alive_r); blk++) {
+        if (alive_l && blk >= LZ_PROBE_AHEAD_L)
+            alive_l = lz_scan_left16(score_tab, tab8, xd, lz_load16(P.tcode + sl - 16), lz_load16(P.qcode + ((s32)sl - diag) - 16), stopl, sl, runl, bestl);
+        if (alive_r)
+            alive_r = lz_scan_right16(score_tab, tab8, xd, lz_load16(P.tcode + sr), lz_load16(P.qcode + ((s32)sr - diag)), stopr, sr, runr, bestr);
     }
     u32 summ = (pos1 - sl) | ((sr - pos1) << 8);
     if (alive_l || alive_r || bestl + bestr >= P.min_score) summ |= LZ_SUMM_SLOW;
@@ -216,19 +307,28 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
         if (!in_hit) {
             // Settle hits straight from their phase-A summaries for as long as that is possible
             // (all but the hits phase A flagged SLOW: possible HSPs and scans that ran into the cap);
-            // the loads of a group of four (key, summary) pairs are issued together.
+            // the loads of a group of LZ_FAST_GROUP (key, summary) pairs are issued together.
             bool start = false;
             for (int budget = LZ_FAST_RUN; budget > 0 && i < i1 && !start; budget--) {
-                u64 k4[4]; u32 s4[4];
-                const u32 n4 = (i1 - i < 4u) ? (i1 - i) : 4u;
-                if (n4 == 4u) { __builtin_memcpy(k4, keys + i, 32); __builtin_memcpy(s4, summ + i, 16); }
-                else for (u32 u = 0; u < n4; u++) { k4[u] = keys[i + u]; s4[u] = summ[i + u]; }
-                u32 u = 0;
-                for (; u < n4; u++) {
-                    const u32 p2 = (u32)k4[u];
+                u64 kk[LZ_FAST_GROUP]; u32 ss[LZ_FAST_GROUP];
+                const u32 ng = (i1 - i < (u32)LZ_FAST_GROUP) ? (i1 - i) : (u32)LZ_FAST_GROUP;
+                if (ng == (u32)LZ_FAST_GROUP) { __builtin_memcpy(kk, keys + i, 8 * LZ_FAST_GROUP); __builtin_memcpy(ss, summ + i, 4 * LZ_FAST_GROUP); }
+                else {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                    for (int u = 0; u < LZ_FAST_GROUP; u++) { kk[u] = ((u32)u < ng) ? keys[i + u] : 0; ss[u] = ((u32)u < ng) ? summ[i + u] : 0; }
+                }
+                u32 taken = ng;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int u = 0; u < LZ_FAST_GROUP; u++) {
+                    if (start || (u32)u >= ng) continue;
+                    const u32 p2 = (u32)kk[u];
                     if (dend > p2 - L) continue;                    // :1113
                     n_ext++;
-                    const u32 sm = s4[u];
+                    const u32 sm = ss[u];
                     if (!(sm & LZ_SUMM_SLOW)) {
                         // The unclipped scans scored below the threshold.  A left scan clipped at
                         // diagEnd walks a prefix of the same bases (its best can only be lower: still
@@ -241,11 +341,11 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
                         continue;
                     }
                     pos2 = p2;
-                    diag = (s32)(u32)(k4[u] >> 32);
+                    diag = (s32)(u32)(kk[u] >> 32);
                     start = true;
-                    break;
+                    taken = (u32)u + 1u;
                 }
-                i += start ? u + 1 : n4;
+                i += taken;
             }
             if (!start) { if (i >= i1) break; continue; }
             pos1 = pos2 + (u32)diag;

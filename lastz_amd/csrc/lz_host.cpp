@@ -108,6 +108,12 @@ int lzh_score_classes(const s32* sub, u8 rowc[256], u8 colc[256], s32 tab[LZ_NCL
     return 0;
 }
 
+u32 lzh_small_classes(const u8 rowc[256], const u8 colc[256])
+{
+    for (int b = 0; b < 256; b++) if (rowc[b] >= 8 || colc[b] >= 8) return 0;
+    return 1;
+}
+
 // src/dna_utilities.c:2888-2936 (compute_entropy with lowerOk == false); same operation order
 double lzh_hsp_entropy(const u8* s, const u8* t, int len)
 {

@@ -9,6 +9,7 @@
 int  lzh_seed_to_dev(const lz_seed_desc* sd, LzSeedDev& d);
 void lzh_make_cls(const u8* score_class /*[256] or NULL*/, const int8_t ctb[256], u8 cls[256]);
 int  lzh_score_classes(const s32* sub, u8 rowc[256], u8 colc[256], s32 tab[LZ_NCLASS * LZ_NCLASS]);
+u32  lzh_small_classes(const u8 rowc[256], const u8 colc[256]);    // 1 when every class id is < 8
 double lzh_hsp_entropy(const u8* s, const u8* t, int len);
 
 struct LzChunk { u32 i0, i1; u64 base, nh; };

@@ -465,6 +465,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     P.tcode = c.target.code_base(); P.tlen = c.geom.tlen;
     P.qcode = qs->code_base();      P.qlen = qlen;
     P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
+    P.cls8 = lzh_small_classes(rowc, colc);
 
     std::vector<lz_hsp> plain;
     // ---- 3. per chunk: fill -> (phase A probe -> stable bucket sort -> bounds -> phase B bucket-serial pass)

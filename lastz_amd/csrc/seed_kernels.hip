@@ -259,10 +259,12 @@ k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* _
              u32* __restrict__ summ)
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
+    __shared__ s32 tab8[64];
     for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_TPB) tab[k] = score_tab_g[k];
+    if (threadIdx.x < 64) tab8[threadIdx.x] = score_tab_g[(threadIdx.x >> 3) * LZ_NCLASS + (threadIdx.x & 7)];
     __syncthreads();
     const u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
-    if (i < n) summ[i] = lz_probe_hit(P, tab, keys[i]);
+    if (i < n) summ[i] = lz_probe_hit(P, tab, P.cls8 ? tab8 : nullptr, keys[i]);
 }
 
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ)

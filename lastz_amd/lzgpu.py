@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblzgpu.so")
+LIB_PATH = os.environ.get("LZGPU_LIB") or os.path.join(_HERE, "liblzgpu.so")   # LZGPU_LIB: try a variant build
 
 MAX_PARTS, MAX_PROBES = 16, 128
 

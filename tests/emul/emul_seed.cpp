@@ -103,6 +103,9 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     std::vector<LzHspRec> recs; std::vector<lz_hsp> plain;
     LzExtendParams P; P.tcode = tc; P.tlen = E.tlen; P.qcode = qc; P.qlen = qlen;
     P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
+    P.cls8 = lzh_small_classes(rowc, colc);
+    s32 tab8[64];
+    for (int k = 0; k < 64; k++) tab8[k] = tab[(k >> 3) * LZ_NCLASS + (k & 7)];
     u64 n_ext = 0, n_bp = 0;
     for (auto& ch : chunks) {
         std::vector<u64> keys(ch.nh);
@@ -111,7 +114,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         if (!a->extend) { for (u64 k : keys) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); } continue; }
         // phase A on the unsorted hits, then the (key, summary) pairs are partitioned together
         std::vector<std::pair<u64, u32>> kv(keys.size());
-        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, keys[i]) };
+        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, P.cls8 ? tab8 : nullptr, keys[i]) };
         std::stable_sort(kv.begin(), kv.end(), [](auto& x, auto& y) { return ((x.first >> 32) & 0xFFFF) < ((y.first >> 32) & 0xFFFF); });
         std::vector<u32> summ(keys.size());
         for (size_t i = 0; i < keys.size(); i++) { keys[i] = kv[i].first; summ[i] = kv[i].second; }
