@@ -13,30 +13,67 @@
 #include "lz_host.hpp"
 #include "lz_gapped_host.hpp"
 
+// Cross-lane data movement inside a wave uses DPP (register-to-register, a few cycles) rather than
+// ds_bpermute shuffles (an LDS round trip each): the row sweep is a chain of short dependent steps, so
+// the latency of these exchanges is what a row costs.  The 7-step inclusive scan is the classic GCN
+// sequence: row_shr 1,2,3 (from the original value), row_shr 4 / 8 on the upper banks, then the last
+// lane of rows 0 and 2 broadcast into rows 1 and 3, then lane 31 into rows 2-3.  Lanes a step does not
+// reach receive the operator's identity, so no lane masks are needed (and the order "lower lanes
+// first" is kept for the non-commutative gap-map composition).
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ s32 lz_dpp(s32 ident, s32 src) { return __builtin_amdgcn_update_dpp(ident, src, CTRL, ROWM, BANKM, false); }
+#define LZ_GAP_IDENT_A (LZ_DP_NEGINF - (1 << 24))                // f(x) = max(A, x - 0) = x for every score x
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ LzDpGap lz_gap_dpp(const LzDpGap& v)
+{
+    LzDpGap t;
+    t.A = lz_dpp<CTRL, ROWM, BANKM>(LZ_GAP_IDENT_A, v.A);
+    t.K = lz_dpp<CTRL, ROWM, BANKM>(0, v.K);
+    t.cut = (u32)lz_dpp<CTRL, ROWM, BANKM>(0, (s32)v.cut);
+    return t;
+}
+#define LZ_WAVE_SCAN(v, x, MOVE, OP)                                   \
+    v = OP(MOVE<0x111, 0xf, 0xf>(x), v);  /* row_shr:1 */               \
+    v = OP(MOVE<0x112, 0xf, 0xf>(x), v);  /* row_shr:2 */               \
+    v = OP(MOVE<0x113, 0xf, 0xf>(x), v);  /* row_shr:3 */               \
+    v = OP(MOVE<0x114, 0xf, 0xe>(v), v);  /* row_shr:4, banks 1-3 */    \
+    v = OP(MOVE<0x118, 0xf, 0xc>(v), v);  /* row_shr:8, banks 2-3 */    \
+    v = OP(MOVE<0x142, 0xa, 0xf>(v), v);  /* row_bcast:15, rows 1,3 */  \
+    v = OP(MOVE<0x143, 0xc, 0xf>(v), v);  /* row_bcast:31, rows 2,3 */
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ s32 lz_max_dpp(s32 v) { return lz_dpp<CTRL, ROWM, BANKM>((s32)0x80000000, v); }
+__device__ __forceinline__ s32 lz_smax(s32 a, s32 b) { return a > b ? a : b; }
+
 struct GpuPhases {                      // X for lz_dp_run: one thread = one lane, barrier after each phase
     LzDpLane regs;
     template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
     template <class F> __device__ __forceinline__ void step(F&& f)  { f((int)threadIdx.x, regs); }
+    // The serial steps of the DPs that share a CU must not all land on the same SIMD (the waves of a
+    // workgroup are dealt out over the four SIMDs in order): the leading wave rotates with the block.
+    int lead_wave;
+    __device__ __forceinline__ int lead_lane() const { return lead_wave << 6; }
+    template <class F> __device__ __forceinline__ void leader(F&& f)
+    {
+        if ((__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave) f();     // a scalar branch: one wave, all its lanes
+        __syncthreads();
+    }
+    __device__ __forceinline__ s32 uni(s32 v) { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((s32)v); }
 
-    // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: wave shuffles inside each wave, per-wave
+    // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: a DPP scan inside each wave, per-wave
     // partials through LDS, then every lane folds in the partials of the waves below it.
     __device__ __forceinline__ s32 scan_gap(LzDpShared& sh, s32 x0)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        LzDpGap inc = { regs.A, regs.K, regs.cut };
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            LzDpGap lo;
-            lo.A = __shfl_up(inc.A, d); lo.K = __shfl_up(inc.K, d); lo.cut = __shfl_up(inc.cut, d);
-            if (wl >= d) inc = lz_dp_gap_compose(lo, inc);
-        }
-        LzDpGap ex;                                              // exclusive inside the wave (lanes wl > 0)
-        ex.A = __shfl_up(inc.A, 1); ex.K = __shfl_up(inc.K, 1); ex.cut = __shfl_up(inc.cut, 1);
+        const LzDpGap x = { regs.A, regs.K, regs.cut };
+        LzDpGap inc = x;
+        LZ_WAVE_SCAN(inc, x, lz_gap_dpp, lz_dp_gap_compose)
+        const LzDpGap ex = lz_gap_dpp<0x138, 0xf, 0xf>(inc);    // wave_shr:1: exclusive (lane 0: identity)
         if (wl == 63) sh.wg[w] = inc;
         __syncthreads();
         s32 xin = x0;                                            // value entering this wave
         for (int j = 0; j < w; j++) xin = lz_dp_gap_apply(sh.wg[j], xin);
-        regs.i_in = (wl == 0) ? xin : lz_dp_gap_apply(ex, xin);
+        regs.i_in = lz_dp_gap_apply(ex, xin);
         s32 xend = x0;
         for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
         return xend;                                            // (wg[] is rewritten a row later, barriers in between)
@@ -44,27 +81,28 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
     __device__ __forceinline__ void scan_cand(LzDpShared& sh, s32 b0)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        s32 inc = regs.cand;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { s32 v = __shfl_up(inc, d); if (wl >= d && v > inc) inc = v; }
-        const s32 ex = __shfl_up(inc, 1);
+        const s32 x = regs.cand;
+        s32 inc = x;
+        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
+        const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
         if (wl == 63) sh.wc[w] = inc;
         __syncthreads();
         s32 pre = b0;
         for (int j = 0; j < w; j++) if (sh.wc[j] > pre) pre = sh.wc[j];
-        regs.run_in = (wl == 0) ? pre : (ex > pre ? ex : pre);
+        regs.run_in = ex > pre ? ex : pre;
     }
     __device__ __forceinline__ void reduce_row(LzDpShared& sh)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
         const s32 lo = has ? (s32)__ffsll((long long)has) - 1 : 0, hi = has ? 63 - (s32)__clzll((long long)has) : 0;
-        const u32 first = __shfl(regs.first, lo), last = __shfl(regs.last, hi);
-        s32 cmax = regs.cand;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { s32 v = __shfl_xor(cmax, d); if (v > cmax) cmax = v; }
+        const u32 first = (u32)__builtin_amdgcn_readlane((s32)regs.first, lo), last = (u32)__builtin_amdgcn_readlane((s32)regs.last, hi);
+        const s32 x = regs.cand;
+        s32 inc = x;
+        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
+        const s32 cmax = __builtin_amdgcn_readlane(inc, 63);
         const u64 att = __ballot(regs.cand == cmax);            // the LAST lane attaining the max owns the column
-        const u32 ccol = __shfl(regs.cand_col, 63 - (s32)__clzll((long long)att));
+        const u32 ccol = (u32)__builtin_amdgcn_readlane((s32)regs.cand_col, 63 - (s32)__clzll((long long)att));
         if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
         __syncthreads();
     }
@@ -90,6 +128,7 @@ k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u3
     __syncthreads();
     const u32 j = job_ids[blockIdx.x];
     GpuPhases x;
+    x.lead_wave = (int)((blockIdx.x + (blockIdx.x >> 8)) & (LZ_DP_WAVES - 1));
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
     lz_dp_run(x, sh, S, P, J, tab, &res[j]);
 }

@@ -92,20 +92,27 @@ struct LzDpShared {
     // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
     LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
     u32 r_first, r_last, r_ccol; s32 r_cmax;
-    // sweep state (written by lane 0)
-    s32 L, R; u32 LY, RY, prevLY, row, cpl, ry_iter;
-    s32 best; u32 end1, end2;
-    s32 left_align, right_align, left_seg, right_seg, list_pos;
-    u32 tb_used, n_act, done, status, truncated;
+    // what lane 0 publishes for the other lanes before each row (its own sweep state is LzDpCtl)
+    u32 LY, row, cpl, ry_iter, n_act, done, trow_cur, b_hi; s32 best;
     u32 extra, fill_n, fill_base, fill_trow, stage_lo, stage_a; s32 fill_i;   // work for all lanes before the next row
-    u32 next_act_row;                     // row at which aligns[order[list_pos]] becomes active
-    u32 b_hi, trow_cur;                   // columns < b_hi are staged in bb[]; tbRow[row] of the current row
-    u32 max_row, min_col, max_col; u64 cells;
-    LzDpSeg lcur, rcur;                   // copies of segs[left_seg] / segs[right_seg]
     // traceback state
     u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
     u8  tb_win[64];
     LzDpActive act[LZ_DP_MAXACT];
+};
+
+// Sweep state of one DP.  Only lane 0 reads and writes it, so it lives in that lane's registers:
+// the row-end / row-set-up step is a serial piece of code that every other lane waits for, and with
+// the state in LDS it was a chain of dependent LDS round trips.
+struct LzDpCtl {
+    s32 L, R; u32 LY, RY, prevLY, row;
+    s32 best; u32 end1, end2;
+    s32 left_align, right_align, left_seg, right_seg, list_pos;
+    u32 tb_used, n_act, done, status, truncated;
+    u32 next_act_row;                     // row at which aligns[order[list_pos]] becomes active
+    u32 b_hi;                             // columns < b_hi are staged in bb[]
+    u32 max_row, min_col, max_col; u64 cells;
+    LzDpSeg lcur, rcur;                   // copies of segs[left_seg] / segs[right_seg]
 };
 
 struct LzDpLane {                       // per-lane values carried between the steps of one row (registers on the GPU)
@@ -124,6 +131,10 @@ struct LzDpLane {                       // per-lane values carried between the s
 //                       its next phase with X::row_result
 //   X::phase(f) runs f on every lane and ends with a barrier; X::step(f) has no barrier: f may touch
 //   only registers and the LDS cells of its own columns, and is followed by a cross-lane step.
+//   X::leader(f) runs the serial piece f() once per DP and ends with a barrier.  On the GPU one whole
+//   wave (the one X::lead_lane() is in) executes it in lockstep on identical data (every lane stores the same values), so that
+//   with its inputs passed through X::uni (value of the first lane = a scalar register) the sweep
+//   state LzDpCtl and the arithmetic on it stay in scalar registers and on the scalar ALU.
 LZ_HD LzDpGap lz_dp_gap_compose(const LzDpGap& f, const LzDpGap& g)      // g after f
 {
     LzDpGap h;
@@ -181,104 +192,113 @@ LZ_HD s32 lz_dp_prev_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, 
 
 LZ_HD u32 lz_dp_special_min(u32 ry, s32 r) { if (r <= 0) return 0; if ((u32)r < ry) return (u32)r; return ry; }
 
+// A value that lane-0 code keeps across rows must not stay "pending on a global load" in the eyes of the
+// compiler: a later use would then wait for vmcnt(0), i.e. for every traceback store still in flight,
+// on every row.  Passing it through X::uni right where it is loaded settles it there.
+template <class X> LZ_HD LzDpSeg lz_dp_uni_seg(X& x, const LzDpSeg& g)
+{ LzDpSeg r; r.b1 = x.uni(g.b1); r.b2 = x.uni(g.b2); r.e1 = x.uni(g.e1); r.e2 = x.uni(g.e2); r.type = x.uni(g.type); return r; }
+
 // update_LR_bounds, src/gapped_extend.c:4588-4700 (lane 0).  The bounding segments change every
-// few hundred rows but are consulted on every row: their fields are kept in LDS (sh.lcur / sh.rcur)
+// few hundred rows but are consulted on every row: their fields are kept in LDS (c.lcur / c.rcur)
 // and re-read from HBM only when next/prev_sweep_seg moves to another segment.
-LZ_HD void lz_dp_update_lr(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+template <class X>
+LZ_HD void lz_dp_update_lr(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJob& J)
 {
-    s32 L = sh.L, R = sh.R; u32 LY = sh.LY, RY = sh.RY;
-    const u32 row = sh.row, a1 = J.anchor1, a2 = J.anchor2;
+    s32 L = c.L, R = c.R; u32 LY = c.LY, RY = c.RY;
+    const u32 row = c.row, a1 = J.anchor1, a2 = J.anchor2;
     if (!J.reversed) {
-        if (sh.left_seg >= 0) {
-            if (sh.lcur.e1 >= row + a1) { if (sh.lcur.type == LZ_DIAG_SEG) L++; }
-            else { L = lz_dp_next_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) + 1; if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg]; }
+        if (c.left_seg >= 0) {
+            if (c.lcur.e1 >= row + a1) { if (c.lcur.type == LZ_DIAG_SEG) L++; }
+            else { L = x.uni(lz_dp_next_sweep_seg(S, 0, c.left_seg, c.left_align, row, a1, a2)) + 1; c.left_seg = x.uni(c.left_seg); c.left_align = x.uni(c.left_align); if (c.left_seg >= 0) c.lcur = lz_dp_uni_seg(x, S.segs[c.left_seg]); }
         }
-        if (sh.left_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
-        if (sh.right_seg >= 0) {
-            if (sh.rcur.e1 >= row + a1) { if (sh.rcur.type == LZ_DIAG_SEG) R++; }
-            else { R = lz_dp_next_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) - 1; if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg]; }
+        if (c.left_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
+        if (c.right_seg >= 0) {
+            if (c.rcur.e1 >= row + a1) { if (c.rcur.type == LZ_DIAG_SEG) R++; }
+            else { R = x.uni(lz_dp_next_sweep_seg(S, 1, c.right_seg, c.right_align, row, a1, a2)) - 1; c.right_seg = x.uni(c.right_seg); c.right_align = x.uni(c.right_align); if (c.right_seg >= 0) c.rcur = lz_dp_uni_seg(x, S.segs[c.right_seg]); }
         }
-        if (sh.right_seg >= 0) RY = lz_dp_special_min(RY, R);
+        if (c.right_seg >= 0) RY = lz_dp_special_min(RY, R);
     } else {
-        if (sh.right_seg >= 0) {
-            if (sh.rcur.b1 <= a1 - row) { if (sh.rcur.type == LZ_DIAG_SEG) L++; }
-            else { L = lz_dp_prev_sweep_seg(S, 1, sh.right_seg, sh.right_align, row, a1, a2) + 1; if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg]; }
+        if (c.right_seg >= 0) {
+            if (c.rcur.b1 <= a1 - row) { if (c.rcur.type == LZ_DIAG_SEG) L++; }
+            else { L = x.uni(lz_dp_prev_sweep_seg(S, 1, c.right_seg, c.right_align, row, a1, a2)) + 1; c.right_seg = x.uni(c.right_seg); c.right_align = x.uni(c.right_align); if (c.right_seg >= 0) c.rcur = lz_dp_uni_seg(x, S.segs[c.right_seg]); }
         }
-        if (sh.right_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
-        if (sh.left_seg >= 0) {
-            if (sh.lcur.b1 <= a1 - row) { if (sh.lcur.type == LZ_DIAG_SEG) R++; }
-            else { R = lz_dp_prev_sweep_seg(S, 0, sh.left_seg, sh.left_align, row, a1, a2) - 1; if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg]; }
+        if (c.right_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
+        if (c.left_seg >= 0) {
+            if (c.lcur.b1 <= a1 - row) { if (c.lcur.type == LZ_DIAG_SEG) R++; }
+            else { R = x.uni(lz_dp_prev_sweep_seg(S, 0, c.left_seg, c.left_align, row, a1, a2)) - 1; c.left_seg = x.uni(c.left_seg); c.left_align = x.uni(c.left_align); if (c.left_seg >= 0) c.lcur = lz_dp_uni_seg(x, S.segs[c.left_seg]); }
         }
-        if (sh.left_seg >= 0) RY = lz_dp_special_min(RY, R);
+        if (c.left_seg >= 0) RY = lz_dp_special_min(RY, R);
     }
-    sh.L = L; sh.R = R; sh.LY = LY; sh.RY = RY;
+    c.L = L; c.R = R; c.LY = LY; c.RY = RY;
 }
 
 // build_active_seg, src/gapped_extend.c:4992-5035: only cells inside [LY,RY] are stamped (that
 // also keeps the ring free of aliases: RY - LY < MAXW)
-LZ_HD void lz_dp_stamp(LzDpShared& sh, u32 x, u32 row) { if (x >= sh.LY && x <= sh.RY) sh.mk[LZ_RING(x)] = row; }
-LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J, LzDpActive& act)
+LZ_HD void lz_dp_stamp(LzDpShared& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = row; }
+LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive& act)
 {
     const LzDpSeg& sg = S.segs[act.seg];
     act.type = sg.type;
     if (!J.reversed) { act.x = sg.b2 - J.anchor2; act.last_row = sg.e1 - J.anchor1; }
     else             { act.x = J.anchor2 - sg.e2; act.last_row = J.anchor1 - sg.b1; }
-    if (act.type != LZ_HORZ_SEG) lz_dp_stamp(sh, act.x, sh.row);
+    if (act.type != LZ_HORZ_SEG) lz_dp_stamp(sh, c, act.x, c.row);
     else {
         u32 horz_end = (!J.reversed) ? sg.e2 - J.anchor2 : J.anchor2 - sg.b2;
-        u32 i_min = sh.LY > act.x ? sh.LY : act.x;
-        u32 i_max = sh.RY < horz_end ? sh.RY : horz_end;
-        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = sh.row;
+        u32 i_min = c.LY > act.x ? c.LY : act.x;
+        u32 i_max = c.RY < horz_end ? c.RY : horz_end;
+        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = c.row;
     }
 }
 
 // row at which the alignment at the head of the above/below list reaches the sweep (or none)
-LZ_HD void lz_dp_peek_list(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+template <class X>
+LZ_HD void lz_dp_peek_list(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJob& J)
 {
-    if (sh.list_pos < 0 || sh.list_pos >= S.n_aligns) { sh.list_pos = -1; sh.next_act_row = 0xFFFFFFFFu; return; }
+    if (c.list_pos < 0 || c.list_pos >= S.n_aligns) { c.list_pos = -1; c.next_act_row = 0xFFFFFFFFu; return; }
     const s32* order = J.reversed ? S.oed : S.obi;
-    const LzDpAlign& al = S.aligns[order[sh.list_pos]];
-    sh.next_act_row = J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1);
+    const LzDpAlign& al = S.aligns[order[c.list_pos]];
+    c.next_act_row = x.uni(J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1));
 }
 
 // update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
-LZ_HD void lz_dp_update_active(const LzDpSnapshot& S, LzDpShared& sh, const LzDpJob& J)
+template <class X>
+LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J)
 {
-    const u32 row = sh.row;
-    for (u32 k = 0; k < sh.n_act; k++) {
+    const u32 row = c.row;
+    for (u32 k = 0; k < c.n_act; k++) {
         LzDpActive& act = sh.act[k];
         if (act.last_row >= row) {
             if (act.type == LZ_DIAG_SEG) act.x++;
-            lz_dp_stamp(sh, act.x, row);
+            lz_dp_stamp(sh, c, act.x, row);
         } else {
             const LzDpAlign& al = S.aligns[act.align];
             s32 nx = J.reversed ? ((act.seg > al.first_seg) ? act.seg - 1 : -1) : ((act.seg < al.last_seg) ? act.seg + 1 : -1);
             if (nx >= 0) {
                 act.seg = nx;
-                lz_dp_build_active(S, sh, J, act);
+                lz_dp_build_active(S, sh, c, J, act);
                 if (act.type == LZ_HORZ_SEG) {
                     act.seg = J.reversed ? act.seg - 1 : act.seg + 1;     // (a horizontal piece is never terminal)
-                    lz_dp_build_active(S, sh, J, act);
+                    lz_dp_build_active(S, sh, c, J, act);
                 }
             } else act.filter = 1;
         }
     }
     // alignments the sweep row now reaches (the reference prepends; order within the list is
-    // immaterial).  The row at which the head of the list starts is cached (sh.next_act_row).
-    while (sh.list_pos >= 0 && sh.next_act_row == row) {
+    // immaterial).  The row at which the head of the list starts is cached (c.next_act_row).
+    while (c.list_pos >= 0 && c.next_act_row == row) {
         const s32* order = J.reversed ? S.oed : S.obi;
-        const LzDpAlign& al = S.aligns[order[sh.list_pos]];
-        if (sh.n_act >= LZ_DP_MAXACT) { sh.status = LZ_DP_ACT_SLOT; sh.done = 1; return; }
-        LzDpActive& act = sh.act[sh.n_act++];
-        act.filter = 0; act.align = order[sh.list_pos];
+        const LzDpAlign& al = S.aligns[order[c.list_pos]];
+        if (c.n_act >= LZ_DP_MAXACT) { c.status = LZ_DP_ACT_SLOT; c.done = 1; return; }
+        LzDpActive& act = sh.act[c.n_act++];
+        act.filter = 0; act.align = order[c.list_pos];
         act.seg = J.reversed ? al.last_seg : al.first_seg;
-        lz_dp_build_active(S, sh, J, act);
-        sh.list_pos++;
-        lz_dp_peek_list(S, sh, J);
+        lz_dp_build_active(S, sh, c, J, act);
+        c.list_pos++;
+        lz_dp_peek_list(x, S, c, J);
     }
     u32 w = 0;                                                 // filter_active_segs(&active, 0)
-    for (u32 k = 0; k < sh.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
-    sh.n_act = w;
+    for (u32 k = 0; k < c.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
+    c.n_act = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,41 +315,42 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
             if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
-                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; res->t_ph[0] = res->t_ph[1] = res->t_ph[2] = res->t_ph[3] = 0; } });
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; for (int q = 0; q < 4; q++) res->t_ph[q] = 0; } });
         return;
     }
 
     const u64 t0 = LZ_CLOCK();
+    LzDpCtl ct;                                                 // lane 0's
     // ---- set-up + row 0 (:3500-3605)
-    x.phase([&](int lane, LzDpLane&) {
-        if (lane != 0) return;
+    x.leader([&]() {
         s32 L = 0, R = (s32)N + 1;
-        if (J.left_seg >= 0)  { const LzDpSeg& g = S.segs[J.left_seg];  L = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) L -= LZ_SDIFF(g.b1, J.anchor1); }
-        if (J.right_seg >= 0) { const LzDpSeg& g = S.segs[J.right_seg]; R = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) R -= LZ_SDIFF(g.b1, J.anchor1); }
+        if (J.left_seg >= 0)  { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.left_seg]);  L = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) L -= LZ_SDIFF(g.b1, J.anchor1); }
+        if (J.right_seg >= 0) { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.right_seg]); R = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) R -= LZ_SDIFF(g.b1, J.anchor1); }
         if (J.reversed) {                                       // note (14), :3536-3541
             if (J.left_seg < 0 && J.right_seg >= 0)       { L = -R + 1; R = (s32)N + 1; }
             else if (J.left_seg >= 0 && J.right_seg < 0)  { R = -L - 1; L = 0; }
             else if (J.left_seg >= 0 && J.right_seg >= 0) { s32 t = -L - 1; L = -R + 1; R = t; }
         }
-        sh.L = L; sh.R = R;
-        sh.left_align = J.left_align; sh.right_align = J.right_align; sh.left_seg = J.left_seg; sh.right_seg = J.right_seg;
-        if (sh.left_seg >= 0) sh.lcur = S.segs[sh.left_seg];
-        if (sh.right_seg >= 0) sh.rcur = S.segs[sh.right_seg];
-        sh.list_pos = J.list_start; sh.n_act = 0;
-        lz_dp_peek_list(S, sh, J);
-        sh.done = 0; sh.status = LZ_DP_OK; sh.truncated = 0;
-        sh.best = 0; sh.end1 = sh.end2 = 0; sh.row = 0; sh.cells = 0;
-        sh.max_row = 0; sh.min_col = 0; sh.max_col = 0;
+        ct.L = L; ct.R = R;
+        ct.left_align = J.left_align; ct.right_align = J.right_align; ct.left_seg = J.left_seg; ct.right_seg = J.right_seg;
+        if (ct.left_seg >= 0) ct.lcur = lz_dp_uni_seg(x, S.segs[ct.left_seg]);
+        if (ct.right_seg >= 0) ct.rcur = lz_dp_uni_seg(x, S.segs[ct.right_seg]);
+        ct.list_pos = J.list_start; ct.n_act = 0;
+        lz_dp_peek_list(x, S, ct, J);
+        ct.done = 0; ct.status = LZ_DP_OK; ct.truncated = 0;
+        ct.best = 0; ct.end1 = ct.end2 = 0; ct.row = 0; ct.cells = 0;
+        ct.max_row = 0; ct.min_col = 0; ct.max_col = 0;
         // row 0: C[0][0]=0, then insertions while the PREVIOUS column's C is >= -yDrop (note 13)
         u32 n0 = 1; s32 prevc = 0, c = -gapOE;
         while (n0 <= N && prevc >= -Y) { prevc = c; c -= gapE; n0++; }
-        if (n0 + LZ_DP_LANES + 72 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; }
-        if (n0 > J.tb_cap || J.row_cap < 2) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; }
-        sh.LY = 0; sh.RY = n0; sh.tb_used = n0; sh.cells = n0;
-        if (!sh.done) trow[0] = 0;
-        sh.b_hi = 1; sh.trow_cur = 0;
-        while (sh.RY + 2 > sh.b_hi) sh.b_hi += LZ_DP_LANES;     // columns [1, b_hi) are staged by the next phase
-        sh.max_col = n0 ? n0 - 1 : 0;
+        if (n0 + LZ_DP_LANES + 72 > LZ_DP_MAXW) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; }
+        if (n0 > J.tb_cap || J.row_cap < 2) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; }
+        ct.LY = 0; ct.RY = n0; ct.tb_used = n0; ct.cells = n0;
+        if (!ct.done) trow[0] = 0;
+        ct.b_hi = 1; sh.trow_cur = 0;
+        while (ct.RY + 2 > ct.b_hi) ct.b_hi += LZ_DP_LANES;     // columns [1, b_hi) are staged by the next phase
+        ct.max_col = n0 ? n0 - 1 : 0;
+        sh.done = ct.done; sh.b_hi = ct.b_hi; sh.ry_iter = n0; sh.row = 0; sh.LY = 0; sh.best = 0; sh.n_act = 0; sh.extra = 0;
     });
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
@@ -337,7 +358,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             for (u32 k = (u32)lane; k < LZ_DP_MAXW; k += LZ_DP_LANES) sh.mk[k] = 0;
             for (u32 col = 1 + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES) sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
             sh.aa[lane] = (1 + (u32)lane <= M) ? (u8)(lz_dp_a(P, J, 1 + (u32)lane) & 31u) : 0;      // rows 1..64
-            for (u32 col = (u32)lane; col < sh.RY; col += LZ_DP_LANES) {
+            for (u32 col = (u32)lane; col < sh.ry_iter; col += LZ_DP_LANES) {
                 s32 c = (col == 0) ? 0 : -gapOE - (s32)(col - 1) * gapE;
                 sh.cc[LZ_RING(col)] = c;
                 sh.dd[LZ_RING(col)] = c - gapOE;
@@ -354,23 +375,24 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
     while (!sh.done) {
         const u64 ts = LZ_CLOCK();
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane != 0) return;
+        x.leader([&]() {
+            [&]() {
             u32 extra = 0;
             if (swept) {
                 // row end: new LY, best/end, right bound, overhang (:3769-3827)
                 u32 first, last, ccol; s32 cmax;
                 x.row_result(sh, first, last, cmax, ccol);
+                first = x.uni(first); last = x.uni(last); cmax = x.uni(cmax); ccol = x.uni(ccol);
                 const u32 iter = RYi - LY0;
-                sh.cells += iter;
-                u32 tb_used = sh.tb_used + iter;
+                ct.cells += iter;
+                u32 tb_used = ct.tb_used + iter;
                 s32 best = best0;
-                if (cmax >= best0) { best = cmax; sh.best = cmax; sh.end1 = row; sh.end2 = ccol; }      // :3731-3735
-                if (first == 0xFFFFFFFFu) { sh.tb_used = tb_used; sh.LY = RYi; sh.done = 1; return; }   // LY >= RY: feasible region empty
-                sh.LY = first;
-                if (LY0 < sh.min_col) sh.min_col = LY0;
-                sh.max_row = row;
-                const s32 NN = (sh.right_seg >= 0 && sh.R > 0) ? sh.R - 1 : (s32)N;
+                if (cmax >= best0) { best = cmax; ct.best = cmax; ct.end1 = row; ct.end2 = ccol; }      // :3731-3735
+                if (first == 0xFFFFFFFFu) { ct.tb_used = tb_used; ct.LY = RYi; ct.done = 1; return; }   // LY >= RY: feasible region empty
+                ct.LY = first;
+                if (LY0 < ct.min_col) ct.min_col = LY0;
+                ct.max_row = row;
+                const s32 NN = (ct.right_seg >= 0 && ct.R > 0) ? ct.R - 1 : (s32)N;
                 u32 RY = RYi, np = 0;
                 if (RY > last + 1) RY = last + 1;
                 else {
@@ -388,35 +410,37 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                     sh.fill_n = 0;
                 } else { sh.fill_n = np; sh.fill_base = RY - np; sh.fill_i = i_last; sh.fill_trow = trow_cur; extra = 1; }
                 tb_used += np;
-                if (RY - 1 > sh.max_col) sh.max_col = RY - 1;
+                if (RY - 1 > ct.max_col) ct.max_col = RY - 1;
                 if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; RY++; }   // terminating cell, :3818-3826
-                sh.RY = RY; sh.tb_used = tb_used;
+                ct.RY = RY; ct.tb_used = tb_used;
                 // B classes of the columns the next row may reach; every LZ_DP_LANES rows the next block of A classes
-                u32 bh = sh.b_hi;
+                u32 bh = ct.b_hi;
                 sh.stage_lo = bh;
                 while (RY + 2 > bh) { bh += LZ_DP_LANES; extra = 1; }
-                sh.b_hi = bh;
+                ct.b_hi = bh;
                 sh.stage_a = ((row & (LZ_DP_LANES - 1)) == 0) ? row + 1 : 0;
                 if (sh.stage_a) extra = 1;
             }
             sh.extra = extra;
             // set-up of the next row: bounds, active segments, traceback budget
-            if (sh.row >= M) { sh.done = 1; return; }
-            sh.row++;
-            sh.prevLY = sh.LY;
-            lz_dp_update_lr(S, sh, J);
-            lz_dp_update_active(S, sh, J);
-            if (sh.done) return;
-            if (sh.RY < sh.LY) sh.RY = sh.LY;                   // note 11
-            const u32 width = sh.RY - sh.LY;
+            if (ct.row >= M) { ct.done = 1; return; }
+            ct.row++;
+            ct.prevLY = ct.LY;
+            lz_dp_update_lr(x, S, ct, J);
+            lz_dp_update_active(x, S, sh, ct, J);
+            if (ct.done) return;
+            if (ct.RY < ct.LY) ct.RY = ct.LY;                   // note 11
+            const u32 width = ct.RY - ct.LY;
             const s32 tb_needed = (s32)width + P.ydrop_tail;
-            if ((s64)sh.tb_used + tb_needed >= (s64)P.tb_len) { sh.truncated = 1; sh.done = 1; sh.row--; return; }   // :3640-3661
-            if ((u64)sh.tb_used + (u64)tb_needed > (u64)J.tb_cap) { sh.status = LZ_DP_TB_SLOT; sh.done = 1; return; }
-            if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > LZ_DP_MAXW) { sh.status = LZ_DP_TOO_WIDE; sh.done = 1; return; }
-            if (sh.row + 1 >= J.row_cap) { sh.status = LZ_DP_ROW_SLOT; sh.done = 1; return; }
-            trow[sh.row] = sh.trow_cur = sh.tb_used - sh.LY;    // tbRow[row], :3662 (u32 wrap intended)
-            sh.ry_iter = sh.RY;
+            if ((s64)ct.tb_used + tb_needed >= (s64)P.tb_len) { ct.truncated = 1; ct.done = 1; ct.row--; return; }   // :3640-3661
+            if ((u64)ct.tb_used + (u64)tb_needed > (u64)J.tb_cap) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; return; }
+            if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > LZ_DP_MAXW) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; return; }
+            if (ct.row + 1 >= J.row_cap) { ct.status = LZ_DP_ROW_SLOT; ct.done = 1; return; }
+            trow[ct.row] = sh.trow_cur = ct.tb_used - ct.LY;    // tbRow[row], :3662 (u32 wrap intended)
+            sh.ry_iter = ct.RY;
             sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
+            }();
+            sh.done = ct.done; sh.row = ct.row; sh.LY = ct.LY; sh.best = ct.best; sh.n_act = ct.n_act; sh.b_hi = ct.b_hi;
         });
         if (sh.done) break;
         if (sh.extra) x.phase([&](int lane, LzDpLane&) {
@@ -433,7 +457,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                 sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
             }
         });
-        row = sh.row; LY0 = sh.LY; RYi = sh.ry_iter; cpl = sh.cpl; best0 = sh.best; trow_cur = sh.trow_cur;
+        row = x.uni(sh.row); LY0 = x.uni(sh.LY); RYi = x.uni(sh.ry_iter); cpl = x.uni(sh.cpl); best0 = x.uni(sh.best); trow_cur = x.uni(sh.trow_cur);
         swept = true;
         const bool any_active = sh.n_act != 0;
         const u32 arow = sh.aa[(row - 1) & (LZ_DP_LANES - 1)];
@@ -476,7 +500,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.A = A; r.K = K; r.cut = cut;
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
-        i_last = x.scan_gap(sh, LZ_DP_NEGINF);
+        i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
         const u64 tb_ = LZ_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.step([&](int lane, LzDpLane& r) {
@@ -568,9 +592,9 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     // in registers (edit_script_add, src/edit_script.c:261-300) and stored once per run.
     const u64 t1 = LZ_CLOCK();
     x.phase([&](int lane, LzDpLane&) {
-        if (lane != 0) return;
-        sh.tb_row = sh.end1; sh.tb_col = sh.end2; sh.tb_prev = 0; sh.tb_nops = 0; sh.tb_run_op = 0; sh.tb_run_len = 0;
-        sh.tb_done = (sh.status != LZ_DP_OK) || !(sh.end1 >= 1 || sh.end2 > 0);
+        if (lane != x.lead_lane()) return;
+        sh.tb_row = ct.end1; sh.tb_col = ct.end2; sh.tb_prev = 0; sh.tb_nops = 0; sh.tb_run_op = 0; sh.tb_run_len = 0;
+        sh.tb_done = (ct.status != LZ_DP_OK) || !(ct.end1 >= 1 || ct.end2 > 0);
     });
     while (!sh.tb_done) {
         x.phase([&](int lane, LzDpLane&) {
@@ -581,9 +605,9 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             sh.tb_win[k] = (u8)v;
         });
         x.phase([&](int lane, LzDpLane&) {
-            if (lane != 0) return;
+            if (lane != x.lead_lane()) return;
             u32 row = sh.tb_row, col = sh.tb_col, prev_op = sh.tb_prev, n_ops = sh.tb_nops;
-            u32 run_op = sh.tb_run_op, run_len = sh.tb_run_len, status = sh.status;
+            u32 run_op = sh.tb_run_op, run_len = sh.tb_run_len, status = ct.status;
             for (u32 k = 0; k < LZ_DP_TBWIN; k++) {
                 if (!(row >= 1 || col > 0)) break;
                 const u32 link = sh.tb_win[k];
@@ -608,15 +632,15 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
                 run_len = 0;
             }
             sh.tb_row = row; sh.tb_col = col; sh.tb_prev = prev_op; sh.tb_nops = n_ops;
-            sh.tb_run_op = run_op; sh.tb_run_len = run_len; sh.status = status; sh.tb_done = fin;
+            sh.tb_run_op = run_op; sh.tb_run_len = run_len; ct.status = status; sh.tb_done = fin;
         });
     }
     x.phase([&](int lane, LzDpLane&) {
-        if (lane != 0) return;
-        res->score = sh.best; res->end1 = sh.end1; res->end2 = sh.end2; res->n_ops = sh.tb_nops;
-        res->status = sh.status; res->truncated = sh.truncated;
-        res->max_row = sh.max_row; res->min_col = sh.min_col; res->max_col = sh.max_col;
-        res->tb_used = sh.tb_used; res->cells = sh.cells;
+        if (lane != x.lead_lane()) return;
+        res->score = ct.best; res->end1 = ct.end1; res->end2 = ct.end2; res->n_ops = sh.tb_nops;
+        res->status = ct.status; res->truncated = ct.truncated;
+        res->max_row = ct.max_row; res->min_col = ct.min_col; res->max_col = ct.max_col;
+        res->tb_used = ct.tb_used; res->cells = ct.cells;
         res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
         res->t_ph[0] = tp0; res->t_ph[1] = tp1; res->t_ph[2] = tp2; res->t_ph[3] = tp3;
     });

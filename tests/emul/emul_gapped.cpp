@@ -13,6 +13,10 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
     LzDpLane lanes[LZ_DP_LANES];
     template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
     template <class F> void step(F&& f)  { for (int l = LZ_DP_LANES - 1; l >= 0; l--) f(l, lanes[l]); }   // no barrier on the GPU: any lane order must do
+    template <class F> void leader(F&& f) { f(); }
+    int lead_lane() const { return 0; }
+    s32 uni(s32 v) { return v; }
+    u32 uni(u32 v) { return v; }
     void row_result(const LzDpShared& sh, u32& first, u32& last, s32& cmax, u32& ccol) { first = sh.r_first; last = sh.r_last; cmax = sh.r_cmax; ccol = sh.r_ccol; }
     s32 scan_gap(LzDpShared&, s32 x0) {
         s32 x = x0;
@@ -58,7 +62,7 @@ struct EmulExec : LzDpExecutor {
                     slot = slot * 4 < tb_len ? slot * 4 : tb_len; retries++;
                     continue;
                 }
-                if (res[k].status != LZ_DP_OK) { fprintf(stderr, "emul: job %zu status %u (row %u LY %u RY %u)\n", k, res[k].status, sh.row, sh.LY, sh.RY); return LZGPU_NH_UNSUPPORTED; }
+                if (res[k].status != LZ_DP_OK) { fprintf(stderr, "emul: job %zu status %u (row %u LY %u)\n", k, res[k].status, sh.row, sh.LY); return LZGPU_NH_UNSUPPORTED; }
                 ops[k].assign(opbuf.begin(), opbuf.begin() + res[k].n_ops);
                 break;
             }
