@@ -114,12 +114,18 @@ def main():
     import torch                                   # before liblzgpu.so: one HIP runtime per process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # "nccl" is RCCL on ROCm.  LZ_BENCH_BACKEND=gloo exists only to exercise this code path with two
+        # ranks on a one-GPU box (RCCL refuses two ranks on the same device); it is not a measured mode.
+        backend = os.environ.get("LZ_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
 

@@ -85,3 +85,19 @@ def oracle_hsps(t, q, masked, pattern=DEFAULT_SEED, with_trans=1, table=None, **
 def ref_run(args, **kw):
     binp = lzo.ref_binary()
     return subprocess.check_output([binp] + args, stderr=subprocess.DEVNULL, **kw).decode()
+
+
+def many_class_scoring():
+    """A matrix with more than 8 distinct rows and columns (IUPAC-style partial credit for R/Y/N and a
+    separate lower-case penalty): takes the kernels off the 8x8 whole-block scan onto the general path."""
+    import numpy as np
+    sub, _ = scoring()
+    m = sub.copy()
+    for amb, members, sc in ((b"R", b"AG", 40), (b"Y", b"CT", 35), (b"K", b"GT", 20), (b"M", b"AC", 15), (b"N", b"ACGT", -10)):
+        a = amb[0]
+        for b in members:
+            m[a, b] = sc; m[b, a] = sc - 5
+        m[a, a] = 50 - a % 7
+    for b in b"acgt":                                           # lower case: half credit against itself / upper case
+        m[b, :] = m[b - 32, :] // 2 - 3; m[:, b] = m[:, b - 32] // 2 - (b % 5)
+    return m

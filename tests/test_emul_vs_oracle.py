@@ -26,8 +26,8 @@ def em():
     return lzgpu.Lib(path=so, prefix="emul_")
 
 
-def _check(em, t, q, pattern=H.DEFAULT_SEED, wt=1, cap=None, step=1, **kw):
-    _, masked = H.scoring()
+def _check(em, t, q, pattern=H.DEFAULT_SEED, wt=1, cap=None, step=1, masked=None, **kw):
+    if masked is None: _, masked = H.scoring()
     ctb = lzo.upper_nuc_to_bits()
     osd = lzo.seed(pattern, wt)
     tab = lzo.Table(t, osd, step=step)
@@ -70,6 +70,15 @@ def test_seeds_steps_thresholds(em):
     _check(em, t, q, pattern="111101101111", wt=1, step=3)
     _check(em, t, q, pattern="11111111", wt=2, hsp_threshold=2000, xdrop=500)
     _check(em, t, q, pattern="1111111111", wt=0, entropic=False, cap=4096)
+
+
+def test_matrix_with_more_than_8_classes(em):
+    """general (masked, 32x32-table) scan path instead of the whole-block 8x8 one"""
+    t, q = seqio.synth_pair(50000, 40000, seed=77, block_min=500, block_max=3000)
+    q = q.copy(); q[::53] = ord("R"); q[7::61] = ord("Y"); q[3000:3500] |= 0x20; q[11::97] = ord("N")
+    m = H.many_class_scoring()
+    assert len({m[i].tobytes() for i in range(256)}) > 8
+    _check(em, t, q, masked=m, hsp_threshold=2200)
 
 
 def test_chunk_planner_splits_inside_a_block(em):

@@ -124,6 +124,18 @@ def test_edge_cases(gpu):
     _same_hsps(gpu, tab3, q3, masked, hsp_threshold=1500)
 
 
+def test_matrix_with_more_than_8_classes(gpu):
+    """general (masked, 32x32-table) scan path instead of the whole-block 8x8 one"""
+    t, q = seqio.synth_pair(150000, 120000, seed=77, block_min=500, block_max=3000)
+    q = q.copy(); q[::53] = ord("R"); q[7::61] = ord("Y"); q[3000:3500] |= 0x20; q[11::97] = ord("N")
+    m = H.many_class_scoring()
+    tab = _prep(gpu, t)
+    for _, _, qq in H.strands(q):
+        _same_hsps(gpu, tab, qq, m, hsp_threshold=2200)
+    _, masked = H.scoring()
+    _same_hsps(gpu, tab, q, masked)                         # and back: the class tables are re-derived
+
+
 def test_diag_hash_collisions_and_long_hsps(gpu):
     """tandem repeats: thousands of hits per hashed diagonal, clipped left extensions"""
     t, q = H.load_case("adversarial")
