@@ -18,12 +18,7 @@ CS = os.path.join(H.ROOT, "lastz_amd", "csrc")
 
 @pytest.fixture(scope="module")
 def L():
-    so = os.path.join(EMUL_DIR, "libemul.so")
-    srcs = [os.path.join(EMUL_DIR, "emul_seed.cpp"), os.path.join(EMUL_DIR, "emul_gapped.cpp"),
-            os.path.join(CS, "lz_host.cpp"), os.path.join(CS, "lz_gapped_host.cpp")]
-    deps = srcs + [os.path.join(CS, f) for f in ("lz_common.hpp", "lz_host.hpp", "lz_dp_dev.hpp", "lz_gapped_host.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+    so = H.build_emul()
     lib = C.CDLL(so)
     lib.emul_gapped_extend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,

@@ -18,11 +18,7 @@ EMUL_DIR = os.path.join(H.ROOT, "tests", "emul")
 
 @pytest.fixture(scope="module")
 def em():
-    so = os.path.join(EMUL_DIR, "libemul.so")
-    srcs = [os.path.join(EMUL_DIR, "emul_seed.cpp"), os.path.join(H.ROOT, "lastz_amd", "csrc", "lz_host.cpp")]
-    deps = srcs + [os.path.join(H.ROOT, "lastz_amd", "csrc", f) for f in ("lz_common.hpp", "lz_host.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+    so = H.build_emul()
     return lzgpu.Lib(path=so, prefix="emul_")
 
 
