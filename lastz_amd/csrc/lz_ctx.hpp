@@ -16,19 +16,19 @@ struct DevBuf {                     // growable device allocation
 };
 
 struct KernelTimer {
-    struct Pending { int id; hipEvent_t a, b; };
+    struct Pending { int id; hipEvent_t a, b; hipStream_t s; };
     bool enabled = false;
     std::vector<std::string> names;
     std::vector<uint64_t> launches;
     std::vector<double> ms;
     std::vector<Pending> pending;
-    std::vector<hipEvent_t> pool;
+    std::map<hipStream_t, std::vector<hipEvent_t>> pool;   // an event is only ever recorded on one stream
     int  id_of(const char* name);
     void begin(const char* name, hipStream_t s);
     void end(hipStream_t s);
     void resolve();                 // after a stream sync: fold pending events into totals
     void reset();
-    hipEvent_t get_event();
+    hipEvent_t get_event(hipStream_t s);
     int cur = -1; hipEvent_t cur_a = nullptr;
 };
 
@@ -65,6 +65,8 @@ struct LzCtx {
 
     // ---- seed-search scratch
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
+    DevBuf wiv, wsk, wsv;           // position index; (word, position) sorted by word
+    u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
     DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
     DevBuf summ_a, summ_b;          // phase-A summaries, travelling with the keys
     DevBuf keys_b2, summ_b2, bstart2;   // second output set (double buffering across chunks)
@@ -92,9 +94,10 @@ int lz_fail(int code, const char* fmt, ...);
 int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev);
 int lzk_table_build(LzCtx& c);
 int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
-int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u64* valid_words_dev);
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys);
+int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out);
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);

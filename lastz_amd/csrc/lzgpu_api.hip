@@ -44,33 +44,37 @@ int KernelTimer::id_of(const char* name)
     names.push_back(name); launches.push_back(0); ms.push_back(0.0);
     return (int)names.size() - 1;
 }
-hipEvent_t KernelTimer::get_event()
+hipEvent_t KernelTimer::get_event(hipStream_t s)
 {
-    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    auto& pl = pool[s];
+    if (!pl.empty()) { hipEvent_t e = pl.back(); pl.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 void KernelTimer::begin(const char* name, hipStream_t s)
 {
     if (!enabled) return;
-    cur = id_of(name); cur_a = get_event();
+    cur = id_of(name); cur_a = get_event(s);
     (void)hipEventRecord(cur_a, s);
 }
 void KernelTimer::end(hipStream_t s)
 {
     if (!enabled || cur < 0) return;
-    hipEvent_t b = get_event();
+    hipEvent_t b = get_event(s);
     (void)hipEventRecord(b, s);
-    pending.push_back({cur, cur_a, b});
+    pending.push_back({cur, cur_a, b, s});
     cur = -1; cur_a = nullptr;
 }
 void KernelTimer::resolve()
 {
+    std::vector<Pending> later;
     for (auto& p : pending) {
         float t = 0.f;
-        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; launches[p.id]++; }
-        pool.push_back(p.a); pool.push_back(p.b);
+        const hipError_t e = hipEventElapsedTime(&t, p.a, p.b);
+        if (e == hipErrorNotReady) { later.push_back(p); continue; }     // recorded after the last synchronisation
+        if (e == hipSuccess) { ms[p.id] += t; launches[p.id]++; }
+        pool[p.s].push_back(p.a); pool[p.s].push_back(p.b);
     }
-    pending.clear();
+    pending.swap(later);
 }
 void KernelTimer::reset() { resolve(); for (auto& x : ms) x = 0; for (auto& x : launches) x = 0; }
 
@@ -125,7 +129,8 @@ extern "C" void lzgpu_shutdown(void)
     (void)hipStreamSynchronize(c.stream);
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2, &c.bstart2,
+    if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2, &c.bstart2,
                        &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
@@ -335,7 +340,7 @@ extern "C" int lzgpu_device_copy(void* dst, const void* src, uint64_t bytes)
 
 #include <chrono>
 struct HostProf {
-    bool on; double t[12]; const char* names[12]; int n = 0;
+    bool on; double t[16]; const char* names[16] = { nullptr }; int n = 0;
     std::chrono::steady_clock::time_point last;
     HostProf() { on = getenv("LZGPU_HOSTPROF") != nullptr; for (auto& x : t) x = 0; }
     void start() { if (on) last = std::chrono::steady_clock::now(); }
@@ -344,7 +349,7 @@ struct HostProf {
         auto now = std::chrono::steady_clock::now();
         t[k] += std::chrono::duration<double, std::milli>(now - last).count(); names[k] = name; if (k >= n) n = k + 1; last = now;
     }
-    ~HostProf() { if (on) for (int k = 0; k < n; k++) fprintf(stderr, "[lzgpu hostprof] %-28s %10.2f ms total\n", names[k], t[k]); }
+    ~HostProf() { if (on) for (int k = 0; k < n; k++) if (names[k]) fprintf(stderr, "[lzgpu hostprof] %-28s %10.2f ms total\n", names[k], t[k]); }
 };
 static HostProf g_hp;
 
@@ -403,6 +408,9 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if ((rc = c.cnt.ensure((size_t)n * 4))) return rc;
     if ((rc = c.off.ensure((size_t)n * 8))) return rc;
     if ((rc = c.pk.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.wiv.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.wsk.ensure((size_t)n * 4))) return rc;
+    if ((rc = c.wsv.ensure((size_t)n * 4))) return rc;
     if ((rc = c.bstart.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
     if ((rc = c.diag_end.ensure((size_t)LZ_DIAG_SIZE * 4))) return rc;
     if ((rc = c.dev_counters.ensure(8 * 8))) return rc;
@@ -413,24 +421,29 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     u64* d_counters = c.dev_counters.as<u64>();                 // [0]=extensions [1]=bp [2]=words
 
     // ---- 1. count + scan
-    if ((rc = lzk_count_hits(c, qs->code_base(), lo, hi, c.cnt.as<u32>(), c.pk.as<u32>(), d_counters + 2))) return rc;
+    if ((rc = lzk_count_hits(c, qs->code_base(), lo, hi, c.cnt.as<u32>(), c.pk.as<u32>(), c.wiv.as<u32>(), c.wsk.as<u32>(), c.wsv.as<u32>(), d_counters + 2))) return rc;
     if ((rc = lzk_scan_counts(c, c.cnt.as<u32>(), c.off.as<u64>(), n))) return rc;
 
-    u64 last_off = 0; u32 last_cnt = 0;
-    LZ_HIP(hipMemcpyAsync(&last_off, c.off.as<u64>() + (n - 1), 8, hipMemcpyDeviceToHost, c.stream));
-    LZ_HIP(hipMemcpyAsync(&last_cnt, c.cnt.as<u32>() + (n - 1), 4, hipMemcpyDeviceToHost, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
-    c.timer.resolve();
-    const u64 total_hits = last_off + last_cnt;
-    g_hp.lap(1, "count+scan (sync)");
-
-    // ---- 2. chunk plan: [i0,i1) in query positions with at most hit_capacity hits each.
-    // Prefix sums are sampled every S positions (one strided copy); finer values are fetched
-    // only if a single S-block exceeds the capacity.
+    // total and the sampled prefix sums for the chunk plan come back through pinned memory the device
+    // writes itself: one synchronisation, no staged device-to-host copies
     const u32 S = 4096;
     const u32 ns = (n + S - 1) / S;
-    std::vector<u64> samp(ns);
-    LZ_HIP(hipMemcpy2D(samp.data(), 8, c.off.p, (size_t)S * 8, 8, ns, hipMemcpyDeviceToHost));
+    if (c.pinned_words < (size_t)ns + 16) {
+        if (c.pinned) (void)hipHostFree(c.pinned);
+        c.pinned = nullptr; c.pinned_words = 0;
+        LZ_HIP(hipHostMalloc((void**)&c.pinned, ((size_t)ns + 16) * 8, hipHostMallocDefault));
+        c.pinned_words = (size_t)ns + 16;
+    }
+    if ((rc = lzk_sample_offsets(c, c.off.as<u64>(), c.cnt.as<u32>(), n, S, ns, c.pinned))) return rc;
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    g_hp.lap(1, "count+scan (sync)");
+    c.timer.resolve();
+    const u64 total_hits = c.pinned[0];
+    const u64* samp = c.pinned + 1;
+
+    // ---- 2. chunk plan: [i0,i1) in query positions with at most hit_capacity hits each.
+    // Prefix sums are sampled every S positions; finer values are fetched only if a single S-block
+    // exceeds the capacity.
     std::vector<LzChunk> chunks;
     hipError_t fetch_err = hipSuccess;
     auto off_at = [&](u32 i) -> u64 {
@@ -477,7 +490,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     static const bool serial = getenv("LZGPU_SERIAL") != nullptr;
     hipStream_t sB = serial ? c.stream : c.stream2;
     for (auto& ch : chunks) {
-        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.cnt.as<u32>(), c.pk.as<u32>(), c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
+        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
             std::vector<u64> hk(ch.nh);
             LZ_HIP(hipMemcpyAsync(hk.data(), c.keys_a.p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));

@@ -159,29 +159,77 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries)
 
 // ------------------------------------------------------------------------------------------
 // B2 step 1: raw hits per query position (private_hit_search + find_table_matches,
-// src/seed_search.c:491-571, 810-875, without calling the processor yet)
+// src/seed_search.c:491-571, 810-875, without calling the processor yet).
+//
+// The table probes are random 4-byte reads into a 64 MiB + 4*Tlen byte structure: taken in query order
+// every probe costs a whole cache line from the fabric (measured: 290 GB per step for k_fill_hits alone).
+// The query positions are therefore visited in the order of their seed words: (word, position) pairs are
+// radix-sorted once per search, and both the count and the fill kernels walk that list, so that each of
+// the 13 probe streams (word ^ flip) moves through wstart[] / wpos[] front to back.  What is written --
+// cnt[position] and the hits at off[position] -- is indexed by position, so the discovery order of the
+// hits is untouched.
 __global__ void __launch_bounds__(LZ_TPB)
-k_count_hits(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd,
-             const u32* __restrict__ wstart, u32* __restrict__ cnt, u32* __restrict__ pk,
-             u64* __restrict__ n_words)
+k_pack_words(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd, u32* __restrict__ pk, u32* __restrict__ iv)
 {
-    u32 i = blockIdx.x * LZ_TPB + threadIdx.x;
-    bool valid = false;
+    // the block's LZ_TPB windows overlap in all but one byte: the codes go through LDS once
+    __shared__ u8 win[LZ_TPB + 32];
+    const u32 i = blockIdx.x * LZ_TPB + threadIdx.x;
+    const u32 L = (u32)sd.length;
+    const s64 first = (s64)lo + (s64)blockIdx.x * LZ_TPB + 1 - (s64)L;     // window start of the block's first position (>= -31: inside the padding)
+    for (u32 k = threadIdx.x; k < LZ_TPB + L - 1; k += LZ_TPB) win[k] = (first + (s64)k < (s64)hi) ? qcode[first + (s64)k] : (u8)LZ_CODE_INVALID;
+    __syncthreads();
     if (i < hi - lo) {
-        u32 packed = 0;
-        cnt[i] = lz_count_hits_at(qcode, lo + i + 1, lo, sd, wstart, valid, packed);
-        pk[i] = packed;                                  // only read where cnt[i] > 0
+        const u32 pos2 = lo + i + 1;
+        u64 w = 0; u32 bad = 0;
+        for (u32 k = 0; k < L; k++) { const u32 c = win[threadIdx.x + k]; bad |= c; w = (w << 2) | LZ_CODE_BITS(c); }
+        const bool valid = pos2 >= lo + L && !(bad & LZ_CODE_INVALID);     // window inside the interval, only ACGT
+        pk[i] = valid ? lz_apply_seed(sd, w) : (1u << sd.weight);   // "no word" sorts after every real word
+        iv[i] = i;
     }
-    u64 b = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long*)n_words, (unsigned long long)__popcll(b));
 }
 
-int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u64* valid_words_dev)
+// "words in seq 2" (the reference's counter): the entries of the sorted list in front of the first "no word"
+__global__ void k_count_words(const u32* __restrict__ sk, u32 n, u32 none, u64* __restrict__ n_words)
 {
-    u32 n = hi - lo;
+    u32 a = 0, b = n;
+    while (a < b) { const u32 m = a + ((b - a) >> 1); if (sk[m] < none) a = m + 1; else b = m; }
+    *n_words += a;
+}
+
+__global__ void __launch_bounds__(LZ_TPB)
+k_count_sorted(const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, LzSeedDev sd,
+               const u32* __restrict__ wstart, u32* __restrict__ cnt)
+{
+    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (j >= n) return;
+    const u32 w0 = sk[j];
+    if (w0 >> sd.weight) return;                                // no word at this position: cnt stays 0
+    u32 c = 0;
+    for (int p = 0; p < sd.nprobes; p++) { const u32 w = w0 ^ sd.probe_xor[p]; c += wstart[w + 1] - wstart[w]; }
+    cnt[sv[j]] = c;
+}
+
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev)
+{
+    const u32 n = hi - lo;
+    LZ_HIP(hipMemsetAsync(cnt, 0, (size_t)n * 4, c.stream));
+    c.timer.begin("k_pack_words", c.stream);
+    hipLaunchKernelGGL(k_pack_words, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       qcode, lo, hi, c.seed, pk, iv);
+    c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
+    size_t tmp = 0;
+    const unsigned bits = (unsigned)c.seed.weight + 1u;
+    LZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, pk, sk, iv, sv, (size_t)n, 0u, bits, c.stream));
+    int rc = c.sort_tmp.ensure(tmp);
+    if (rc) return rc;
+    c.timer.begin("rocprim_sort_words", c.stream);
+    LZ_HIP(rocprim::radix_sort_pairs(c.sort_tmp.p, tmp, pk, sk, iv, sv, (size_t)n, 0u, bits, c.stream));
+    c.timer.end(c.stream);
+    hipLaunchKernelGGL(k_count_words, dim3(1), dim3(1), 0, c.stream, sk, n, 1u << c.seed.weight, valid_words_dev);
     c.timer.begin("k_count_hits", c.stream);
-    hipLaunchKernelGGL(k_count_hits, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
-                       qcode, lo, hi, c.seed, c.wstart.as<u32>(), cnt, pk, valid_words_dev);
+    hipLaunchKernelGGL(k_count_sorted, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                       sk, sv, n, c.seed, c.wstart.as<u32>(), cnt);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -202,52 +250,84 @@ int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n)
     return 0;
 }
 
+// total number of hits and every stride-th prefix sum, written straight into pinned host memory:
+// out[0] = total, out[1 + k] = off[k * stride]
+__global__ void __launch_bounds__(LZ_TPB)
+k_sample_offsets(const u64* __restrict__ off, const u32* __restrict__ cnt, u32 n, u32 stride, u32 ns, u64* __restrict__ out)
+{
+    const u32 k = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (k < ns) out[1 + k] = off[(size_t)k * stride];
+    if (k == 0) out[0] = off[n - 1] + cnt[n - 1];
+}
+
+int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out)
+{
+    hipLaunchKernelGGL(k_sample_offsets, dim3((ns + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream, off, cnt, n, stride, ns, out);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
 // B2 step 2: materialise the hits of query positions [i0,i1) in discovery order.
-// 16 lanes per query position, one probe (exact word / transition flip) per lane: each lane reads
-// its word's CSR range, a 16-lane prefix sum places the probes' lists back to back in probe order
-// (= the reference's enumeration order within a position, src/seed_search.c:522-549), and the 4
-// positions of a wave write one contiguous window of the hit array.
+// A wave takes 64 entries of the word-sorted list, keeps those whose position lies in [i0,i1) (the hit
+// arrays hold one chunk of positions at a time) and serves them four at a time: 16 lanes per position, one
+// probe (exact word / transition flip) per lane.  Each lane reads its word's CSR range, a 16-lane prefix
+// sum places the probes' lists back to back in probe order (= the reference's enumeration order within a
+// position, src/seed_search.c:522-549), and the lists go to off[position] in the hit array.
 #define LZ_FILL_GROUP 16
 __global__ void __launch_bounds__(LZ_TPB)
 k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
-            const u32* __restrict__ cnt, const u32* __restrict__ pk, const u64* __restrict__ off,
+            const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
             u64 base, u64* __restrict__ keys)
 {
-    const u32 gid = (blockIdx.x * LZ_TPB + threadIdx.x) / LZ_FILL_GROUP;
-    const u32 p   = threadIdx.x & (LZ_FILL_GROUP - 1);
-    const u32 i   = i0 + gid;
-    const bool have = (i < i1) && (cnt[i] != 0);        // uniform across the 16-lane group
-    const u32 packed = have ? pk[i] : 0;
-    const u32 pos2 = lo + i + 1;
-    u64* out = have ? keys + (off[i] - base) : keys;
-    u32 carry = 0;
-    for (int r = 0; r < sd.nprobes; r += LZ_FILL_GROUP) {   // uniform trip count
-        u32 a = 0, len = 0;
-        if (have && r + (int)p < sd.nprobes) {
-            const u32 w = packed ^ sd.probe_xor[r + p];
-            a = wstart[w]; len = wstart[w + 1] - a;
-        }
-        u32 incl = len;                                  // inclusive prefix over the 16-lane group
+    const u32 lane = threadIdx.x & 63u, p = lane & (LZ_FILL_GROUP - 1), g = lane >> 4;
+    const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane
+    u32 w_l = 0, i_l = 0; bool in = false;
+    if (j < n) { w_l = sk[j]; i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
+    u64 todo = __ballot(in);
+    while (todo) {                                              // wave-uniform
+        // the next four entries of the wave, one per 16-lane group
+        int src = -1;
+        u64 m = todo;
 #pragma unroll
-        for (int d = 1; d < LZ_FILL_GROUP; d <<= 1) {
-            u32 v = __shfl_up(incl, d, LZ_FILL_GROUP);
-            if ((int)p >= d) incl += v;
+        for (int q = 0; q < 4; q++) {
+            const int s_q = m ? (int)__ffsll((long long)m) - 1 : -1;
+            if (m) m &= m - 1;
+            if ((int)g == q) src = s_q;
         }
-        const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
-        u64* o = out + carry + (incl - len);
-        for (u32 j = 0; j < len; j++) o[j] = lz_hit_key(wpos[a + j], pos2);
-        carry += total;
+        todo = m;
+        const bool have = src >= 0;
+        const u32 packed = __shfl(w_l, have ? src : 0);
+        const u32 i = __shfl(i_l, have ? src : 0);
+        const u32 pos2 = lo + i + 1;
+        u64* out = have ? keys + (off[i] - base) : keys;
+        u32 carry = 0;
+        for (int r = 0; r < sd.nprobes; r += LZ_FILL_GROUP) {   // uniform trip count
+            u32 a = 0, len = 0;
+            if (have && r + (int)p < sd.nprobes) {
+                const u32 w = packed ^ sd.probe_xor[r + p];
+                a = wstart[w]; len = wstart[w + 1] - a;
+            }
+            u32 incl = len;                                  // inclusive prefix over the 16-lane group
+#pragma unroll
+            for (int d = 1; d < LZ_FILL_GROUP; d <<= 1) {
+                u32 v = __shfl_up(incl, d, LZ_FILL_GROUP);
+                if ((int)p >= d) incl += v;
+            }
+            const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
+            u64* o = out + carry + (incl - len);
+            for (u32 jj = 0; jj < len; jj++) o[jj] = lz_hit_key(wpos[a + jj], pos2);
+            carry += total;
+        }
     }
 }
 
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* cnt, const u32* pk, const u64* off, u64 base, u64* keys)
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys)
 {
-    u64 n = (u64)(i1 - i0) * LZ_FILL_GROUP;
-    if (n == 0) return 0;
+    if (n == 0 || i1 <= i0) return 0;
     c.timer.begin("k_fill_hits", c.stream);
-    hipLaunchKernelGGL(k_fill_hits, dim3((unsigned)((n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
-                       lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), cnt, pk, off, base, keys);
+    hipLaunchKernelGGL(k_fill_hits, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                       lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -399,3 +479,4 @@ int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u
     LZ_HIP(hipGetLastError());
     return 0;
 }
+
