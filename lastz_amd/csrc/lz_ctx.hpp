@@ -69,9 +69,8 @@ struct LzCtx {
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
     DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
     DevBuf summ_a, summ_b;          // phase-A summaries, travelling with the keys
-    DevBuf keys_b2, summ_b2, bstart2;   // second output set (double buffering across chunks)
+    DevBuf keys_b2, summ_b2;        // second output set (double buffering across chunks)
     DevBuf sort_tmp, scan_tmp;
-    DevBuf bstart;                  // [LZ_DIAG_SIZE+1]
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
     DevBuf score_tab;               // [32*32] s32
     DevBuf hsp_out, hsp_count;      // candidates + counter
@@ -102,6 +101,5 @@ int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);
 int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n);
-int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart, hipStream_t s);
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, u32 n, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

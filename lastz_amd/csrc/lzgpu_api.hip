@@ -53,6 +53,8 @@ hipEvent_t KernelTimer::get_event(hipStream_t s)
 void KernelTimer::begin(const char* name, hipStream_t s)
 {
     if (!enabled) return;
+    static const char* only = getenv("LZGPU_TIMER_ONLY");        // profiling aid: time just this kernel
+    if (only && strcmp(only, name) != 0) { cur = -1; return; }
     cur = id_of(name); cur_a = get_event(s);
     (void)hipEventRecord(cur_a, s);
 }
@@ -66,12 +68,25 @@ void KernelTimer::end(hipStream_t s)
 }
 void KernelTimer::resolve()
 {
+    // LZGPU_GAPS=1 (profiling aid): idle time on a stream between the end of one timed kernel and the
+    // start of the next, reported when it exceeds 0.3 ms
+    static const bool gaps = getenv("LZGPU_GAPS") != nullptr;
+    static std::map<hipStream_t, Pending> last;
     std::vector<Pending> later;
     for (auto& p : pending) {
         float t = 0.f;
         const hipError_t e = hipEventElapsedTime(&t, p.a, p.b);
         if (e == hipErrorNotReady) { later.push_back(p); continue; }     // recorded after the last synchronisation
         if (e == hipSuccess) { ms[p.id] += t; launches[p.id]++; }
+        if (gaps) {
+            auto it = last.find(p.s);
+            float g = 0.f;
+            if (it != last.end() && hipEventElapsedTime(&g, it->second.b, p.a) == hipSuccess && g > 0.3f)
+                fprintf(stderr, "[lzgpu gaps] %.2f ms idle between %s and %s\n", g, names[it->second.id].c_str(), names[p.id].c_str());
+            if (it != last.end()) { pool[it->second.s].push_back(it->second.a); pool[it->second.s].push_back(it->second.b); }
+            last[p.s] = p;
+            continue;
+        }
         pool[p.s].push_back(p.a); pool[p.s].push_back(p.b);
     }
     pending.swap(later);
@@ -117,6 +132,7 @@ extern "C" int lzgpu_init(int device_index)
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_extended[k], hipEventDisableTiming));
     }
     LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_init, hipEventDisableTiming));
+    if (const char* hc = getenv("LZGPU_HIT_CAPACITY")) { const long long v = atoll(hc); if (v >= 1024) g_ctx.hit_capacity = (u64)v; }
     g_ctx.device = device_index;
     g_ctx.inited = true;
     return 0;
@@ -130,8 +146,8 @@ extern "C" void lzgpu_shutdown(void)
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
     if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2, &c.bstart2,
-                       &c.sort_tmp, &c.scan_tmp, &c.bstart, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2,
+                       &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
     for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); }
@@ -411,7 +427,6 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if ((rc = c.wiv.ensure((size_t)n * 4))) return rc;
     if ((rc = c.wsk.ensure((size_t)n * 4))) return rc;
     if ((rc = c.wsv.ensure((size_t)n * 4))) return rc;
-    if ((rc = c.bstart.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
     if ((rc = c.diag_end.ensure((size_t)LZ_DIAG_SIZE * 4))) return rc;
     if ((rc = c.dev_counters.ensure(8 * 8))) return rc;
     if ((rc = c.hsp_count.ensure(4))) return rc;
@@ -468,7 +483,6 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (a->extend && chunks.size() > 1) {
             if ((rc = c.keys_b2.ensure((size_t)max_chunk * 8))) return rc;
             if ((rc = c.summ_b2.ensure((size_t)max_chunk * 4))) return rc;
-            if ((rc = c.bstart2.ensure(((size_t)LZ_DIAG_SIZE + 1) * 4))) return rc;
         }
     }
     const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
@@ -504,14 +518,12 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         const int set = (int)(ci & 1);
         u64* kb = set ? c.keys_b2.as<u64>() : c.keys_b.as<u64>();
         u32* sb = set ? c.summ_b2.as<u32>() : c.summ_b.as<u32>();
-        u32* bs = set ? c.bstart2.as<u32>() : c.bstart.as<u32>();
         if ((rc = lzk_probe_hits(c, P, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.summ_a.as<u32>()))) return rc;
         if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
         if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), kb, c.summ_a.as<u32>(), sb, ch.nh))) return rc;
         LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
         LZ_HIP(hipStreamWaitEvent(sB, c.ev_sorted[set], 0));
-        if ((rc = lzk_bucket_bounds(c, kb, ch.nh, bs, sB))) return rc;
-        if ((rc = lzk_extend(c, P, kb, sb, bs, c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+        if ((rc = lzk_extend(c, P, kb, sb, (u32)ch.nh, c.diag_end.as<u32>(), c.score_tab.as<s32>(),
                              c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, sB))) return rc;
         LZ_HIP(hipEventRecord(c.ev_extended[set], sB));
         ci++;

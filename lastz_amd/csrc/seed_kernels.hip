@@ -373,30 +373,10 @@ int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ
     return 0;
 }
 
-__global__ void __launch_bounds__(LZ_TPB)
-k_bucket_bounds(const u64* __restrict__ keys, u64 n, u32* __restrict__ bstart)
-{
-    u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
-    if (i > n) return;
-    s32 bp = (i == 0) ? -1 : (s32)((keys[i - 1] >> 32) & (LZ_DIAG_SIZE - 1));
-    s32 b  = (i == n) ? (s32)LZ_DIAG_SIZE : (s32)((keys[i] >> 32) & (LZ_DIAG_SIZE - 1));
-    for (s32 w = bp + 1; w <= b; w++) bstart[w] = (u32)i;
-}
-
-int lzk_bucket_bounds(LzCtx& c, const u64* keys, u64 n, u32* bstart, hipStream_t s)
-{
-    c.timer.begin("k_bucket_bounds", s);
-    hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)((n + 1 + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, s,
-                       keys, n, bstart);
-    c.timer.end(s);
-    LZ_HIP(hipGetLastError());
-    return 0;
-}
-
 // B2 step 5 (phase B): one lane per hash bucket
 #define LZ_EXT_TPB 64
 __global__ void __launch_bounds__(LZ_EXT_TPB)
-k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ summ, const u32* __restrict__ bstart,
+k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ summ, u32 n,
          u32* __restrict__ diag_end, const s32* __restrict__ score_tab_g,
          LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap, u64* __restrict__ counters)
 {
@@ -404,7 +384,16 @@ k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__
     for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_EXT_TPB) tab[k] = score_tab_g[k];
     __syncthreads();
     const u32 h = blockIdx.x * LZ_EXT_TPB + threadIdx.x;
-    const u32 i0 = bstart[h], i1 = bstart[h + 1];
+    // the lane's bucket = the run of keys whose bits 32..47 equal h (the array is partitioned by them):
+    // two binary searches, 2 x 28 dependent loads once per launch instead of a pass over all keys
+    u32 i0 = 0, i1 = 0;
+    {
+        u32 a = 0, b = n;
+        while (a < b) { const u32 m = a + ((b - a) >> 1); if ((u32)((keys[m] >> 32) & (LZ_DIAG_SIZE - 1)) < h) a = m + 1; else b = m; }
+        i0 = a; b = n;
+        while (a < b) { const u32 m = a + ((b - a) >> 1); if ((u32)((keys[m] >> 32) & (LZ_DIAG_SIZE - 1)) <= h) a = m + 1; else b = m; }
+        i1 = a;
+    }
     u64 n_ext = 0, n_bp = 0;
     if (i0 < i1) {
         u32 d = lz_extend_bucket(P, tab, keys, summ, i0, i1, diag_end[h], n_ext, n_bp,
@@ -422,12 +411,12 @@ k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__
     }
 }
 
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, const u32* bstart, u32* diag_end,
+int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, u32 n, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
     c.timer.begin("k_extend", s);
     hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, s,
-                       P, keys, summ, bstart, diag_end, score_tab, out, out_count, out_cap, counters);
+                       P, keys, summ, n, diag_end, score_tab, out, out_count, out_cap, counters);
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -479,4 +468,5 @@ int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u
     LZ_HIP(hipGetLastError());
     return 0;
 }
+
 
