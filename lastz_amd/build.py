@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

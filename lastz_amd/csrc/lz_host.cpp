@@ -2,6 +2,8 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <thread>
+#include <vector>
 #include "lz_host.hpp"
 
 // strict-seed compilation, restating src/seeds.c:321-640 (parse_one_seed; flips in
@@ -147,7 +149,10 @@ static bool host_window_word(const u8* seq, u32 pos, const LzSeedDev& sd, const 
     return true;
 }
 
-struct RecKey { u32 pos2, probe, pos1, idx; };
+// discovery order of the candidates: query position up, probe order, target position down
+// (src/seed_search.c:506-533, :832) -- one 64-bit key (pos2 | probe | ~pos1's upper bits would not fit, so
+// two words) compared lexicographically
+struct RecKey { u64 hi; u32 lo, idx; };       // hi = pos2 << 32 | probe, lo = ~pos1
 
 int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
@@ -165,27 +170,48 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
             for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break;
         }
         if (probe >= (u32)sd.nprobes) return LZGPU_ERR_STATE;
-        order[i] = { recs[i].seed_pos2, probe, recs[i].seed_pos1, i };
+        order[i] = { ((u64)recs[i].seed_pos2 << 32) | probe, ~recs[i].seed_pos1, i };
     }
-    std::sort(order.begin(), order.end(), [](const RecKey& x, const RecKey& y) {
-        if (x.pos2 != y.pos2) return x.pos2 < y.pos2;
-        if (x.probe != y.probe) return x.probe < y.probe;
-        return x.pos1 > y.pos1;
-    });
+    // The GPU is idle while this runs (the call is synchronous): four threads for the sort and the
+    // entropy factors once there are enough candidates to pay for starting them.
+    auto less = [](const RecKey& x, const RecKey& y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; };
+    const u32 T = n_rec >= 16384 ? 4u : 1u;
+    auto part = [&](u32 t) { return (u32)((u64)n_rec * t / T); };
+    auto run = [&](auto&& fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (u32 t = 1; t < T; t++) th.emplace_back(fn, t);
+        fn(0u);
+        for (auto& x : th) x.join();
+    };
+    run([&](u32 t) { std::sort(order.begin() + part(t), order.begin() + part(t + 1), less); });
+    if (T == 4) {
+        run([&](u32 t) { if (t < 2) std::inplace_merge(order.begin() + part(2 * t), order.begin() + part(2 * t + 1), order.begin() + part(2 * t + 2), less); });
+        std::inplace_merge(order.begin(), order.begin() + part(2), order.end(), less);
+    }
     const s32 zero_thresh = K > 0 ? K : 0;                      // src/lastz.c:2937-2939
-    for (u32 k = 0; k < n_rec; k++) {
-        const LzHspRec& r = recs[order[k].idx];
-        s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
-        u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
-        s32 sim = r.score;
-        if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
-            const u32* mc = match_counts ? match_counts + 5 * (size_t)order[k].idx : nullptr;
-            double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
-                          : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
-            sim = (s32)(sim * q);                               // "similarity *= q" on an s32 score
+    std::vector<s32> sims(n_rec);
+    run([&](u32 t) {
+        for (u32 k = part(t); k < part(t + 1); k++) {
+            const LzHspRec& r = recs[order[k].idx];
+            s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+            u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
+            s32 sim = r.score;
+            if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
+                const u32* mc = match_counts ? match_counts + 5 * (size_t)order[k].idx : nullptr;
+                double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
+                              : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
+                sim = (s32)(sim * q);                           // "similarity *= q" on an s32 score
+            }
+            sims[k] = sim;
         }
-        if (sim < K) continue;
-        out.push_back({ pos1, pos2, length, sim });
+    });
+    out.reserve(n_rec);
+    for (u32 k = 0; k < n_rec; k++) {
+        if (sims[k] < K) continue;
+        const LzHspRec& r = recs[order[k].idx];
+        const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+        out.push_back({ r.end1, (u32)((s32)r.end1 - diag), r.length, sims[k] });
     }
     return 0;
 }

@@ -113,5 +113,5 @@ def build_emul():
             os.path.join(cs, "lz_host.cpp"), os.path.join(cs, "lz_gapped_host.cpp")]
     deps = srcs + [os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "lzgpu.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so] + srcs)
     return so
