@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--qlen", type=int, default=10_000_000)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--nogapped", action="store_true")
+    ap.add_argument("--gpu-only", action="store_true", help="run only lastz_gpu; report wall, LAV size and sha256 to compare with an earlier full run")
     a = ap.parse_args()
     t, q = seqio.synth_pair(a.tlen, a.qlen, seed=a.seed)
     flags = ["--nogapped"] if a.nogapped else ["--ydrop=9430"]
@@ -32,7 +33,7 @@ def main():
         seqio.write_fasta(os.path.join(d, "q.fa"), [("query", q)])
         res = {}
         outs = {}
-        for name in ("lastz_gpu", "lastz"):
+        for name in (("lastz_gpu",) if a.gpu_only else ("lastz_gpu", "lastz")):
             t0 = time.time()
             p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", name), "t.fa", "q.fa"] + flags, cwd=d,
                                capture_output=True, text=True)
@@ -40,6 +41,12 @@ def main():
             if p.returncode != 0:
                 print(p.stderr[-2000:]); sys.exit(1)
             outs[name] = normalize_lav(p.stdout)
+        import hashlib
+        res["lav_sha256"] = {k: hashlib.sha256(v.encode()).hexdigest() for k, v in outs.items()}
+        if a.gpu_only:
+            res.update({"tlen": a.tlen, "qlen": a.qlen, "flags": flags, "lav_bytes": len(outs["lastz_gpu"]),
+                        "alignment_blocks": outs["lastz_gpu"].count("a {")})
+            print(json.dumps(res)); return
         res.update({"tlen": a.tlen, "qlen": a.qlen, "flags": flags, "lav_bytes": len(outs["lastz"]),
                     "alignment_blocks": outs["lastz"].count("a {"), "byte_identical": outs["lastz"] == outs["lastz_gpu"],
                     "speedup": round(res["lastz_wall_s"] / res["lastz_gpu_wall_s"], 1),
