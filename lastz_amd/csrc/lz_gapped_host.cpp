@@ -2,8 +2,12 @@
 // DPs are delegated to an LzDpExecutor (the HIP executor in dp_kernels.hip).
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <unordered_map>
 #include "lz_gapped_host.hpp"
+#include "lz_host.hpp"
 
 #define SUBM(m, r, c) ((m)[((size_t)(r) << 8) | (size_t)(c)])
 enum { OP_INS = 1, OP_DEL = 2, OP_SUB = 3 };
@@ -46,13 +50,27 @@ static bool seg_before(const lz_segment& a, const lz_segment& b)
 struct Neighbours { s32 la, ls, ra, rs; };
 
 // msp_left_right, src/gapped_extend.c:3953-4028.  rc: 1 = ok, 0 = anchor lies on an alignment, -1 = internal
+// The reference walks every alignment that starts at or before pos1; only those that also end at or
+// after pos1 matter.  With the running maximum of end1 along the start order (obi_maxend) the walk goes
+// backwards from the last alignment starting <= pos1 and stops where nothing earlier can reach pos1;
+// the survivors are then visited in the reference's (ascending) order, which decides ties.
 static int msp_left_right(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbours& nb)
 {
     u32 right = 0xFFFFFFFFu, left = 0xFFFFFFFFu;
     nb.la = nb.ls = nb.ra = nb.rs = -1;
-    for (size_t o = 0; o < S.obi.size(); o++) {
+    size_t lo = 0, hi = S.obi.size();                          // first o with aligns[obi[o]].pos1 > pos1
+    while (lo < hi) { const size_t m = (lo + hi) / 2; if (S.aligns[S.obi[m]].pos1 > pos1) hi = m; else lo = m + 1; }
+    size_t cand[64]; size_t nc = 0; bool overflow = false;
+    for (size_t o = hi; o-- > 0; ) {
+        if (S.obi_maxend[o] < pos1) break;
+        if (S.aligns[S.obi[o]].end1 < pos1) continue;
+        if (nc == 64) { overflow = true; break; }
+        cand[nc++] = o;
+    }
+    const size_t n_visit = overflow ? hi : nc;
+    for (size_t v = 0; v < n_visit; v++) {
+        const size_t o = overflow ? v : cand[nc - 1 - v];
         const LzDpAlign& al = S.aligns[S.obi[o]];
-        if (al.pos1 > pos1) break;
         if (al.end1 < pos1) continue;
         s32 bp = -1;
         for (s32 k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].e1 >= pos1) { bp = k; break; }
@@ -110,6 +128,9 @@ static void insert_align(LzHostSnapshot& S, s32 ai)
     p = 0;
     while (p < S.oed.size() && S.aligns[S.oed[p]].end1 > m.end1) p++;
     S.oed.insert(S.oed.begin() + p, ai);
+    S.obi_maxend.resize(S.obi.size());
+    u32 mx = 0;
+    for (size_t o = 0; o < S.obi.size(); o++) { const u32 e = S.aligns[S.obi[o]].end1; if (e > mx) mx = e; S.obi_maxend[o] = mx; }
 }
 
 // score_alignment, src/gapped_extend.c:5631-5675
@@ -233,8 +254,15 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     if (G.tlen == G.qlen && memcmp(G.t, G.q, G.tlen) == 0) return LZGPU_NH_IDENTICAL;   // :1152-1189 not restated
     if (G.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
 
-    std::sort(anchors, anchors + n_anchors, seg_before);       // batched_segments, :1675
+    // LZGPU_HOSTPROF=1: where the host time of the stage goes
+    static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
+    double t_sort = 0, t_window = 0, t_exec = 0, t_commit = 0;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](double& acc) { const double t = now(); acc += t - t_mark; t_mark = t; };
+    lzh_sort4(anchors, anchors + n_anchors, seg_before);       // batched_segments, :1675
     st.anchors = n_anchors;
+    lap(t_sort);
 
     LzHostSnapshot S;
     struct Info { s32 s; u32 beg1, beg2, end1, end2; std::vector<u32> script; };
@@ -258,10 +286,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::unordered_map<u32, Cached> cache;
     std::vector<Entry> entries;
     std::vector<u32> fresh;                                    // anchors launched in this round
-    std::vector<std::pair<s64, s64>> chosen;                   // (diag, pos1) of selected anchors, this window
+    std::unordered_map<s64, std::vector<std::pair<s64, s64>>> chosen_grid;   // (diag, pos1) of selected anchors, this window
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        jobs.clear(); entries.clear(); chosen.clear(); fresh.clear();
+        jobs.clear(); entries.clear(); chosen_grid.clear(); fresh.clear();
         u32 j = next;
         const u32 scan_limit = 64 * W;
         const size_t n_snap = S.aligns.size();
@@ -273,14 +301,21 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (ok == 0) { cache.erase(j); continue; }         // on an earlier alignment: gone for good
             const s64 dg = (s64)a1 - (s64)a2;
             auto hit = cache.find(j);
+            // (the selected anchors are kept in cells of NEAR_DIAG diagonals: a near one is in the anchor's
+            // cell or one next to it -- a window scans up to 64 K anchors against up to 1 K selected ones)
+            const s64 cell = (dg >= 0 ? dg : dg - (NEAR_DIAG - 1)) / NEAR_DIAG;
             if (hit == cache.end()) {
                 bool defer = false;
-                for (auto& c : chosen)
-                    if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
-                        c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) { defer = true; break; }
+                for (s64 cc = cell - 1; cc <= cell + 1 && !defer; cc++) {
+                    auto g = chosen_grid.find(cc);
+                    if (g == chosen_grid.end()) continue;
+                    for (auto& c : g->second)
+                        if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
+                            c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) { defer = true; break; }
+                }
                 if (defer) { entries.push_back({ j, false }); continue; }
             }
-            chosen.push_back({ dg, (s64)a1 });
+            chosen_grid[cell].push_back({ dg, (s64)a1 });
             entries.push_back({ j, true });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
@@ -298,6 +333,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             cache.emplace(j, std::move(cr));
             fresh.push_back(j);
         }
+        lap(t_window);
         if (entries.empty()) { next = j; break; }
         if (!jobs.empty()) {
             res.assign(jobs.size(), LzDpResult());
@@ -311,6 +347,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             }
         }
         st.rounds++; st.dp_runs += jobs.size();
+        lap(t_exec);
 
         // ---- commit in the reference's order
         bool cut = false;
@@ -365,7 +402,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             insert_align(S, (s32)S.aligns.size() - 1);
         }
         if (!cut) next = j;
+        lap(t_commit);
     }
+    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, commit %.2f ms (%u rounds)\n",
+                      t_sort, t_window, t_exec, t_commit, (unsigned)st.rounds);
 
     // ---- output in increasing start order (orderBegInc), :1475-1566
     for (s32 ai : S.obi) {

@@ -18,6 +18,7 @@ struct LzHostSnapshot {
     std::vector<LzDpAlign> aligns;
     std::vector<LzDpSeg>   segs;
     std::vector<s32>       obi, oed;
+    std::vector<u32>       obi_maxend;     // obi_maxend[o] = max end1 of aligns[obi[0..o]] (host index for msp_left_right)
 };
 
 struct LzDpExecutor {

@@ -57,3 +57,23 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
                     std::vector<lz_hsp>& out, const u32* match_counts = nullptr);
 double lzh_entropy_from_counts(int cA, int cC, int cG, int cT, int len);
+
+// std::sort on four threads (quarters, then two merges) for the host phases during which the GPU
+// waits; `less` must be a strict weak order (elements it ties are interchangeable for the callers).
+#include <algorithm>
+#include <thread>
+template <class It, class Less>
+void lzh_sort4(It first, It last, Less less)
+{
+    const size_t n = (size_t)(last - first);
+    if (n < 16384) { std::sort(first, last, less); return; }
+    It q[5] = { first, first + n / 4, first + n / 2, first + (3 * n) / 4, last };
+    std::thread t1([&] { std::sort(q[1], q[2], less); }), t2([&] { std::sort(q[2], q[3], less); }), t3([&] { std::sort(q[3], q[4], less); });
+    std::sort(q[0], q[1], less);
+    t1.join(); t2.join(); t3.join();
+    std::thread t4([&] { std::inplace_merge(q[2], q[3], q[4], less); });
+    std::inplace_merge(q[0], q[1], q[2], less);
+    t4.join();
+    std::inplace_merge(q[0], q[2], q[4], less);
+}
+
