@@ -283,7 +283,7 @@ struct HipDpExec : LzDpExecutor {
 
 static u32 g_dp_slot_tb = 8u << 20;
 extern "C" int lzgpu_set_dp_slot(uint32_t bytes) { if (bytes < 65536) return LZGPU_ERR_ARG; g_dp_slot_tb = bytes; return 0; }
-static u32 g_dp_window = 1024;
+static u32 g_dp_window = 2048;       // anchors speculated per round (a 50 Mbp strand has ~1150 that need a DP: one full launch instead of two)
 extern "C" int lzgpu_set_dp_window(uint32_t n) { if (n < 1) return LZGPU_ERR_ARG; g_dp_window = n; return 0; }
 
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len);     // lzgpu_api.hip
@@ -338,6 +338,7 @@ extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint
     G.t = c.target.host.data(); G.tlen = tlen; G.q = qhost; G.qlen = qlen; G.sub = a->sub;
     G.gap_open = a->gap_open; G.gap_extend = a->gap_extend; G.ydrop = a->ydrop; G.score_thresh = a->score_thresh;
     G.window = g_dp_window;
+    if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
     if (a->reduce) lzh_reduce_to_points(G.t, G.q, G.sub, a->anchors, a->n_anchors);
     std::vector<lz_align> al; std::vector<u32> op; LzGappedStats st;
     rc = lzh_gapped_extend(G, ex, a->anchors, a->n_anchors, al, op, st);
