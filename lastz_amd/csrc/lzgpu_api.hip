@@ -378,8 +378,6 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_prepare has not been called");
 
     g_hp.start();
-    auto abs_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    if (g_hp.on) fprintf(stderr, "[lzgpu abs] %.3f enter\n", abs_ms());
     // ---- query
     SeqSlot* qs;
     if (a->query) {
@@ -452,10 +450,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         c.pinned_words = (size_t)ns + 16;
     }
     if ((rc = lzk_sample_offsets(c, c.off.as<u64>(), c.cnt.as<u32>(), n, S, ns, c.pinned))) return rc;
-    if (g_hp.on) fprintf(stderr, "[lzgpu abs] %.3f count phase queued\n", abs_ms());
     LZ_HIP(hipStreamSynchronize(c.stream));
     g_hp.lap(1, "count+scan (sync)");
-    if (g_hp.on) fprintf(stderr, "[lzgpu abs] %.3f count phase done\n", abs_ms());
     c.timer.resolve();
     const u64 total_hits = c.pinned[0];
     const u64* samp = c.pinned + 1;
@@ -568,7 +564,6 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     LZ_HIP(hipStreamSynchronize(c.stream));
     c.timer.resolve();
     g_hp.lap(5, "copy candidates");
-    if (g_hp.on) fprintf(stderr, "[lzgpu abs] %.3f candidates on host\n", abs_ms());
     std::vector<lz_hsp> fin;
     if ((rc = lzh_finish_hsps(recs.data(), n_rec, c.target.host.data(), qhost, c.seed, c.geom.char_to_bits,
                               a->hsp_threshold, a->entropic, fin, gpu_counts ? mc.data() : nullptr)))
