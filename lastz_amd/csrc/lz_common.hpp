@@ -109,6 +109,7 @@ struct LzExtendParams {
     s32 min_score;                 // candidates with left+right >= min_score are emitted
     u32 seed_len;
     u32 cls8;                      // every scoring class of either sequence is < 8: lz_scan16_fast is usable
+    const u8* tnib; const u8* qnib; // 4-bit class codes, base i = nibble i + LZ_SEQ_PAD (NULL unless cls8)
 };
 
 struct LzVec16 { u32 w[4]; };
@@ -142,6 +143,25 @@ LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); r
 // Returns the number of bases that passed (16: the scan goes on; otherwise the scan consumed one
 // more base, the failing one, and stopped).  run is meaningless after a failure.
 #define LZ_SCAN_POISON (-(1 << 30))
+LZ_HD u32 lz_xdrop_chain16(const s32 sc[16], s32 xd, s32& run, s32& best)
+{
+    s32 p = run, thr = best - xd;
+    u32 nok = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; k++) {
+        p += sc[k];
+        const bool ok = p >= thr;
+        nok += ok ? 1u : 0u;
+        const s32 t = p - xd;
+        thr = t > thr ? t : thr;
+        p = ok ? p : LZ_SCAN_POISON;
+    }
+    run = p; best = thr + xd;
+    return nok;
+}
+
 template <bool REV>
 LZ_HD u32 lz_scan16_fast(const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv, s32& run, s32& best)
 {
@@ -158,21 +178,34 @@ LZ_HD u32 lz_scan16_fast(const s32* tab8, s32 xd, const LzVec16& tv, const LzVec
         const int b = REV ? 15 - k : k;
         sc[k] = *(const s32*)((const u8*)tab8 + ((x[b >> 2] >> ((b & 3) * 8)) & 0xFFu));
     }
-    s32 p = run, thr = best - xd;
-    u32 nok = 0;
+    return lz_xdrop_chain16(sc, xd, run, best);
+}
+
+// The same block from 4-bit class codes, two bases per byte (tn[0], tn[1] = 16 target nibbles in
+// sequence order, lowest nibble first; likewise qn): phase A is bound by its 16-byte gathers as much
+// as by its arithmetic, and packed codes halve the gathers.  Even and odd nibbles are turned into
+// table addresses separately (four bases per instruction pair again).
+template <bool REV>
+LZ_HD u32 lz_scan16_nib(const s32* tab8, s32 xd, const u32 tn[2], const u32 qn[2], s32& run, s32& best)
+{
+    u32 xe[2], xo[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int d = 0; d < 2; d++) {
+        xe[d] = ((tn[d] & 0x07070707u) << 5) | ((qn[d] & 0x07070707u) << 2);
+        xo[d] = ((tn[d] << 1) & 0xE0E0E0E0u) | ((qn[d] >> 2) & 0x1C1C1C1Cu);
+    }
+    s32 sc[16];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < 16; k++) {
-        p += sc[k];
-        const bool ok = p >= thr;
-        nok += ok ? 1u : 0u;
-        const s32 t = p - xd;
-        thr = t > thr ? t : thr;
-        p = ok ? p : LZ_SCAN_POISON;
+        const int m = REV ? 15 - k : k;                         // nibble of the block
+        const u32 w = (m & 1) ? xo[m >> 3] : xe[m >> 3];
+        sc[k] = *(const s32*)((const u8*)tab8 + ((w >> (((m & 7) >> 1) * 8)) & 0xFFu));
     }
-    run = p; best = thr + xd;
-    return nok;
+    return lz_xdrop_chain16(sc, xd, run, best);
 }
 
 // One 16-base block of the left scan (loop 1, :2623-2632: bases sl-1, sl-2, ... taken from the
@@ -225,24 +258,76 @@ LZ_HD bool lz_scan_right16(const s32* score_tab, const s32* tab8, s32 xd, const 
     return go && ((s32)sr < stopr);
 }
 
-// Phase A of one hit.  The scans are memory-latency bound (a random target line per hit), and the
-// address of every block is known from the key alone: the first LZ_PROBE_AHEAD_L / _R blocks of
-// both sequences are loaded before any of them is scored, so a hit costs two dependent memory round
-// trips (key, blocks) instead of one per block; the few scans that are still going after that
-// continue block by block.  (The 64 bytes of padding around the sequences cover the blocks that
-// reach over either end.)
+// Phase A of one hit, in two parts.
+// lz_probe_head: the address of every block is known from the key alone, so the first
+// LZ_PROBE_AHEAD_L / _R blocks of both sequences are loaded before any of them is scored (two
+// dependent memory round trips per hit: key, blocks) and scanned; most hits end inside them.
+// lz_scan_continue: a scan that is still going continues block by block, up to the cap.  The two
+// scans of a hit are independent (loop 2 restarts at the seed end, :2663-2682), so the kernel hands
+// the unfinished ones to other lanes as separate tasks (seed_kernels.hip); lz_probe_hit is the plain
+// composition.  (The 64 bytes of padding around the sequences cover blocks that reach over an end.)
 #ifndef LZ_PROBE_AHEAD_L
-#define LZ_PROBE_AHEAD_L 2
-#define LZ_PROBE_AHEAD_R 1
+#define LZ_PROBE_AHEAD_L 3
+#define LZ_PROBE_AHEAD_R 2
 #endif
-LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key)
+// 4-bit codes: nibble n of the array is base n - LZ_SEQ_PAD.  `cnt` dwords (8 bases each) starting AT
+// base `base` (any parity): whole 16-byte loads from the byte that holds it, then a 4-bit funnel shift.
+template <int NLOAD>
+LZ_HD void lz_load_nib(const u8* nib, s64 base, u32* out /*[4*NLOAD - 1]*/)
+{
+    const s64 n = base + LZ_SEQ_PAD;
+    const u8* p = nib + (n >> 1);
+    const u32 sh = (u32)(n & 1) * 4u;
+    u32 raw[4 * NLOAD];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < NLOAD; k++) { const LzVec16 v = lz_load16(p + 16 * k); raw[4 * k] = v.w[0]; raw[4 * k + 1] = v.w[1]; raw[4 * k + 2] = v.w[2]; raw[4 * k + 3] = v.w[3]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4 * NLOAD - 1; j++) out[j] = (u32)(((((u64)raw[j + 1]) << 32) | raw[j]) >> sh);
+}
+
+struct LzProbeSt { u32 pos1; s32 diag, stopl, stopr; u32 sl, sr; s32 runl, bestl, runr, bestr; bool alive_l, alive_r; };
+
+LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key, LzProbeSt& st)
 {
     const s32 xd = P.xdrop;
     const u32 pos2 = (u32)key;
     const s32 diag = (s32)(u32)(key >> 32);
     const u32 pos1 = pos2 + (u32)diag;
-    const s32 stopl = diag > 0 ? diag : 0;                                               // diagEnd == 0
-    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
+    st.pos1 = pos1; st.diag = diag;
+    st.stopl = diag > 0 ? diag : 0;                                                      // diagEnd == 0
+    st.stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
+    st.sl = st.sr = pos1;
+    st.runl = st.bestl = st.runr = st.bestr = 0;
+    st.alive_l = ((s32)st.sl > st.stopl) && (0 >= -xd);
+    st.alive_r = ((s32)st.sr < st.stopr) && (0 >= -xd);
+    if (tab8 && P.tnib && xd >= 0 && (s32)pos1 - st.stopl >= 16 * LZ_PROBE_AHEAD_L && st.stopr - (s32)pos1 >= 16 * LZ_PROBE_AHEAD_R) {
+        // every block of the window is a whole one: 16 (L+R) x 8 bases from three 16-byte loads per sequence
+        u32 tw[11], qw[11];
+        lz_load_nib<3>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, tw);
+        lz_load_nib<3>(P.qnib, (s64)pos2 - 16 * LZ_PROBE_AHEAD_L, qw);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int b = 0; b < LZ_PROBE_AHEAD_L; b++) {
+            if (st.alive_l) {
+                const int d = 2 * (LZ_PROBE_AHEAD_L - 1 - b);
+                const u32 nok = lz_scan16_nib<true>(tab8, xd, tw + d, qw + d, st.runl, st.bestl);
+                st.sl -= (nok < 16u) ? nok + 1u : 16u;
+                st.alive_l = nok == 16u && (s32)st.sl > st.stopl;
+            }
+            if (b < LZ_PROBE_AHEAD_R && st.alive_r) {
+                const int d = 2 * (LZ_PROBE_AHEAD_L + b);
+                const u32 nok = lz_scan16_nib<false>(tab8, xd, tw + d, qw + d, st.runr, st.bestr);
+                st.sr += (nok < 16u) ? nok + 1u : 16u;
+                st.alive_r = nok == 16u && (s32)st.sr < st.stopr;
+            }
+        }
+        return;
+    }
     const u8* tp = P.tcode + pos1;
     const u8* qp = P.qcode + pos2;
     LzVec16 tl[LZ_PROBE_AHEAD_L], ql[LZ_PROBE_AHEAD_L], tr[LZ_PROBE_AHEAD_R], qr[LZ_PROBE_AHEAD_R];
@@ -254,26 +339,54 @@ LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32*
 #pragma unroll
 #endif
     for (int b = 0; b < LZ_PROBE_AHEAD_R; b++) { tr[b] = lz_load16(tp + 16 * b); qr[b] = lz_load16(qp + 16 * b); }
-    u32 sl = pos1, sr = pos1;
-    s32 runl = 0, bestl = 0, runr = 0, bestr = 0;
-    bool alive_l = ((s32)sl > stopl) && (0 >= -xd);
-    bool alive_r = ((s32)sr < stopr) && (0 >= -xd);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int b = 0; b < LZ_PROBE_AHEAD_L; b++) {
-        if (alive_l) alive_l = lz_scan_left16(score_tab, tab8, xd, tl[b], ql[b], stopl, sl, runl, bestl);
-        if (b < LZ_PROBE_AHEAD_R && alive_r) alive_r = lz_scan_right16(score_tab, tab8, xd, tr[b], qr[b], stopr, sr, runr, bestr);
+        if (st.alive_l) st.alive_l = lz_scan_left16(score_tab, tab8, xd, tl[b], ql[b], st.stopl, st.sl, st.runl, st.bestl);
+        if (b < LZ_PROBE_AHEAD_R && st.alive_r) st.alive_r = lz_scan_right16(score_tab, tab8, xd, tr[b], qr[b], st.stopr, st.sr, st.runr, st.bestr);
     }
-    for (int blk = LZ_PROBE_AHEAD_R; blk < LZ_PROBE_CAP / 16 && (alive_l || alive_r); blk++) {
-        if (alive_l && blk >= LZ_PROBE_AHEAD_L)
-            alive_l = lz_scan_left16(score_tab, tab8, xd, lz_load16(P.tcode + sl - 16), lz_load16(P.qcode + ((s32)sl - diag) - 16), stopl, sl, runl, bestl);
-        if (alive_r)
-            alive_r = lz_scan_right16(score_tab, tab8, xd, lz_load16(P.tcode + sr), lz_load16(P.qcode + ((s32)sr - diag)), stopr, sr, runr, bestr);
+}
+
+// continue one scan for at most `blocks` further blocks; returns whether it is still alive (at the cap)
+template <bool RIGHT>
+LZ_HD bool lz_scan_continue(const LzExtendParams& P, const s32* score_tab, const s32* tab8, s32 diag, s32 stop,
+                            u32& s, s32& run, s32& best, int blocks)
+{
+    bool alive = true;
+    for (; blocks > 0 && alive; blocks--) {
+        const u32 room = RIGHT ? (u32)(stop - (s32)s) : (u32)((s32)s - stop);
+        if (tab8 && P.tnib && room >= 16u && P.xdrop >= 0) {
+            u32 tn[3], qn[3];
+            const s64 b1 = RIGHT ? (s64)s : (s64)s - 16;
+            lz_load_nib<1>(P.tnib, b1, tn);
+            lz_load_nib<1>(P.qnib, b1 - diag, qn);
+            const u32 nok = lz_scan16_nib<!RIGHT>(tab8, P.xdrop, tn, qn, run, best);
+            const u32 c = nok < 16u ? nok + 1u : 16u;
+            s = RIGHT ? s + c : s - c;
+            alive = nok == 16u && (RIGHT ? (s32)s < stop : (s32)s > stop);
+            continue;
+        }
+        if (RIGHT) alive = lz_scan_right16(score_tab, tab8, P.xdrop, lz_load16(P.tcode + s), lz_load16(P.qcode + ((s32)s - diag)), stop, s, run, best);
+        else       alive = lz_scan_left16(score_tab, tab8, P.xdrop, lz_load16(P.tcode + s - 16), lz_load16(P.qcode + ((s32)s - diag) - 16), stop, s, run, best);
     }
-    u32 summ = (pos1 - sl) | ((sr - pos1) << 8);
-    if (alive_l || alive_r || bestl + bestr >= P.min_score) summ |= LZ_SUMM_SLOW;
+    return alive;
+}
+
+LZ_HD u32 lz_probe_summary(const LzExtendParams& P, const LzProbeSt& st)
+{
+    u32 summ = (st.pos1 - st.sl) | ((st.sr - st.pos1) << 8);
+    if (st.alive_l || st.alive_r || st.bestl + st.bestr >= P.min_score) summ |= LZ_SUMM_SLOW;
     return summ;
+}
+
+LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key)
+{
+    LzProbeSt st;
+    lz_probe_head(P, score_tab, tab8, key, st);
+    if (st.alive_l) st.alive_l = lz_scan_continue<false>(P, score_tab, tab8, st.diag, st.stopl, st.sl, st.runl, st.bestl, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
+    if (st.alive_r) st.alive_r = lz_scan_continue<true>(P, score_tab, tab8, st.diag, st.stopr, st.sr, st.runr, st.bestr, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
+    return lz_probe_summary(P, st);
 }
 
 // ---- phase B.  One bucket (= one value of hashedDiag) of the diagonal hash: process its hits of this chunk

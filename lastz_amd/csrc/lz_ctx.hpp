@@ -36,6 +36,8 @@ struct SeqSlot {                    // a sequence resident in HBM
     DevBuf raw;                     // LZ_SEQ_PAD + len + LZ_SEQ_PAD bytes
     DevBuf code;                    // same geometry, code bytes (see lz_common.hpp)
     DevBuf dp;                      // same geometry, DP score-class codes (unmasked scoring), B3 only
+    DevBuf nib;                     // 4-bit class codes, two bases per byte (phase A; built when all classes are < 8)
+    bool   have_nib = false;
     u32    len = 0;
     bool   have_raw = false;
     uint64_t code_key = 0;          // hash of the (class map, charToBits) the codes were built with
@@ -91,6 +93,7 @@ int lz_fail(int code, const char* fmt, ...);
 
 // ---- launchers implemented in seed_kernels.hip (all asynchronous on ctx.stream) ----
 int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev);
+int lzk_pack_nibbles(LzCtx& c, const u8* code_alloc, u8* nib, size_t nbytes);
 int lzk_table_build(LzCtx& c);
 int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);

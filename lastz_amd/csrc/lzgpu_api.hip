@@ -150,8 +150,8 @@ extern "C" void lzgpu_shutdown(void)
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); }
-    c.target.dp.release();
+    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); }
+    c.target.dp.release(); c.target.nib.release();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
     if (c.stream2) (void)hipStreamDestroy(c.stream2);
@@ -198,6 +198,17 @@ static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
     LZ_HIP(hipStreamSynchronize(c.stream));          // cls is caller stack memory
     if ((rc = lzk_encode(c, s.raw_base(), s.code_base(), s.len, cls_dev.as<u8>()))) return rc;
     s.code_key = key;
+    // packed 4-bit codes for phase A when the matrix has fewer than 8 classes
+    bool small = true;
+    for (int b = 0; b < 256; b++) if ((cls[b] & 31u) >= 8u) { small = false; break; }
+    s.have_nib = false;
+    if (small) {
+        const size_t total = (size_t)s.len + 2 * LZ_SEQ_PAD + 16;   // the code allocation (even)
+        if ((rc = s.nib.ensure(total / 2 + 64))) return rc;
+        LZ_HIP(hipMemsetAsync(s.nib.p, 0, total / 2 + 64, c.stream));
+        if ((rc = lzk_pack_nibbles(c, s.code.as<u8>(), s.nib.as<u8>(), total / 2))) return rc;
+        s.have_nib = true;
+    }
     return 0;
 }
 
@@ -493,6 +504,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     P.qcode = qs->code_base();      P.qlen = qlen;
     P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
     P.cls8 = lzh_small_classes(rowc, colc);
+    const bool nibs = P.cls8 && c.target.have_nib && qs->have_nib;
+    P.tnib = nibs ? c.target.nib.as<u8>() : nullptr; P.qnib = nibs ? qs->nib.as<u8>() : nullptr;
 
     std::vector<lz_hsp> plain;
     // ---- 3. per chunk: fill -> (phase A probe -> stable bucket sort -> bounds -> phase B bucket-serial pass)

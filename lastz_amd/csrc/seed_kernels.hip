@@ -39,6 +39,21 @@ k_encode(const u8* __restrict__ raw, u8* __restrict__ code, u32 len, const u8* _
     }
 }
 
+// 4-bit class codes for phase A: nib[b] = class(code[2b]) | class(code[2b+1]) << 4, over the whole padded
+// code array (padding bytes carry class 0 there and here)
+__global__ void __launch_bounds__(LZ_TPB)
+k_pack_nibbles(const u8* __restrict__ code, u8* __restrict__ nib, size_t nbytes)
+{
+    const size_t b = (size_t)blockIdx.x * LZ_TPB + threadIdx.x;
+    if (b < nbytes) nib[b] = (u8)((code[2 * b] & 7u) | ((code[2 * b + 1] & 7u) << 4));
+}
+int lzk_pack_nibbles(LzCtx& c, const u8* code_alloc, u8* nib, size_t nbytes)
+{
+    hipLaunchKernelGGL(k_pack_nibbles, dim3((unsigned)((nbytes + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream, code_alloc, nib, nbytes);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
 int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev)
 {
     if (len == 0) return 0;
@@ -333,18 +348,53 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
     return 0;
 }
 
-// B2 step 3 (phase A): one thread per raw hit, any order -- capped X-drop scans, 4-byte summary
+// B2 step 3 (phase A): one thread per raw hit, any order -- capped X-drop scans, 4-byte summary.
+// The kernel is VALU-bound (PMC: 92 % VALU, 79 % texture-address busy), and the scan lengths inside a wave
+// differ: after the blocks every hit gets in lz_probe_head, ~20 % of the left and ~10 % of the right scans
+// are still going, and a wave that serves them in place issues every further block for all 64 lanes.  The
+// unfinished scans of the 256 hits of a block are therefore queued in LDS as independent tasks (left ones
+// from the front, right ones from the back) and served densely: one lane per task, to completion.
+struct LzScanTask { u32 s; s32 run, best, stop, diag; u32 side; };
 __global__ void __launch_bounds__(LZ_TPB)
 k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* __restrict__ score_tab_g,
              u32* __restrict__ summ)
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
     __shared__ s32 tab8[64];
+    __shared__ LzScanTask task[2 * LZ_TPB];
+    __shared__ u32 n_left, n_right;
     for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_TPB) tab[k] = score_tab_g[k];
     if (threadIdx.x < 64) tab8[threadIdx.x] = score_tab_g[(threadIdx.x >> 3) * LZ_NCLASS + (threadIdx.x & 7)];
+    if (threadIdx.x == 0) { n_left = 0; n_right = 0; }
     __syncthreads();
+    const s32* t8 = P.cls8 ? tab8 : nullptr;
     const u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
-    if (i < n) summ[i] = lz_probe_hit(P, tab, P.cls8 ? tab8 : nullptr, keys[i]);
+    LzProbeSt st;
+    st.alive_l = st.alive_r = false;
+    if (i < n) lz_probe_head(P, tab, t8, keys[i], st);
+    int slot_l = -1, slot_r = -1;
+    if (st.alive_l) {
+        slot_l = (int)atomicAdd(&n_left, 1u);
+        task[slot_l] = { st.sl, st.runl, st.bestl, st.stopl, st.diag, 0u };
+    }
+    if (st.alive_r) {
+        slot_r = 2 * LZ_TPB - 1 - (int)atomicAdd(&n_right, 1u);
+        task[slot_r] = { st.sr, st.runr, st.bestr, st.stopr, st.diag, 1u };
+    }
+    __syncthreads();
+    const u32 nl = n_left, nr = n_right;
+    for (u32 k = threadIdx.x; k < nl + nr; k += LZ_TPB) {
+        LzScanTask& q = task[k < nl ? k : 2 * LZ_TPB - 1 - (k - nl)];
+        u32 s = q.s; s32 run = q.run, best = q.best;
+        bool alive;
+        if (q.side) alive = lz_scan_continue<true>(P, tab, t8, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
+        else        alive = lz_scan_continue<false>(P, tab, t8, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
+        q.s = s; q.best = best; q.run = alive ? 1 : 0;          // the result goes back through the task's slot
+    }
+    __syncthreads();
+    if (slot_l >= 0) { st.sl = task[slot_l].s; st.bestl = task[slot_l].best; st.alive_l = task[slot_l].run != 0; }
+    if (slot_r >= 0) { st.sr = task[slot_r].s; st.bestr = task[slot_r].best; st.alive_r = task[slot_r].run != 0; }
+    if (i < n) summ[i] = lz_probe_summary(P, st);
 }
 
 int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ)

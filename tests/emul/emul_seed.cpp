@@ -104,6 +104,16 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     LzExtendParams P; P.tcode = tc; P.tlen = E.tlen; P.qcode = qc; P.qlen = qlen;
     P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = L;
     P.cls8 = lzh_small_classes(rowc, colc);
+    // 4-bit codes as the device builds them (k_pack_nibbles), with slack for whole 16-byte loads
+    auto nibbles = [](const std::vector<u8>& code) {
+        std::vector<u8> nb(code.size() / 2 + 80, 0);
+        for (size_t b = 0; 2 * b + 1 < code.size(); b++) nb[b] = (u8)((code[2 * b] & 7u) | ((code[2 * b + 1] & 7u) << 4));
+        return nb;
+    };
+    std::vector<u8> tnib, qnib;
+    const bool use_nib = P.cls8 && !getenv("EMUL_NO_NIBBLES");
+    if (use_nib) { tnib = nibbles(E.tcode); qnib = nibbles(qcode); }
+    P.tnib = use_nib ? tnib.data() : nullptr; P.qnib = use_nib ? qnib.data() : nullptr;
     s32 tab8[64];
     for (int k = 0; k < 64; k++) tab8[k] = tab[(k >> 3) * LZ_NCLASS + (k & 7)];
     u64 n_ext = 0, n_bp = 0;
