@@ -289,6 +289,7 @@ LZ_HD void lz_load_nib(const u8* nib, s64 base, u32* out /*[4*NLOAD - 1]*/)
     for (int j = 0; j < 4 * NLOAD - 1; j++) out[j] = (u32)(((((u64)raw[j + 1]) << 32) | raw[j]) >> sh);
 }
 
+#define LZ_PROBE_NLOAD ((16 * (LZ_PROBE_AHEAD_L + LZ_PROBE_AHEAD_R) + 1 + 31) / 32)   // 16-byte loads covering the window at either parity
 struct LzProbeSt { u32 pos1; s32 diag, stopl, stopr; u32 sl, sr; s32 runl, bestl, runr, bestr; bool alive_l, alive_r; };
 
 LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key, LzProbeSt& st)
@@ -305,10 +306,10 @@ LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s3
     st.alive_l = ((s32)st.sl > st.stopl) && (0 >= -xd);
     st.alive_r = ((s32)st.sr < st.stopr) && (0 >= -xd);
     if (tab8 && P.tnib && xd >= 0 && (s32)pos1 - st.stopl >= 16 * LZ_PROBE_AHEAD_L && st.stopr - (s32)pos1 >= 16 * LZ_PROBE_AHEAD_R) {
-        // every block of the window is a whole one: 16 (L+R) x 8 bases from three 16-byte loads per sequence
-        u32 tw[11], qw[11];
-        lz_load_nib<3>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, tw);
-        lz_load_nib<3>(P.qnib, (s64)pos2 - 16 * LZ_PROBE_AHEAD_L, qw);
+        // every block of the window is a whole one: LZ_PROBE_NLOAD 16-byte loads per sequence
+        u32 tw[4 * LZ_PROBE_NLOAD - 1], qw[4 * LZ_PROBE_NLOAD - 1];
+        lz_load_nib<LZ_PROBE_NLOAD>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, tw);
+        lz_load_nib<LZ_PROBE_NLOAD>(P.qnib, (s64)pos2 - 16 * LZ_PROBE_AHEAD_L, qw);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
