@@ -5,6 +5,7 @@ set -u
 O=gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 600 python bench.py --gapped > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof_stats.err
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
