@@ -146,7 +146,7 @@ k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ re
 }
 
 struct DpBufs {
-    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out;
+    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act;
 };
 static DpBufs g_dp;
 
@@ -167,11 +167,13 @@ struct HipDpExec : LzDpExecutor {
         if ((rc = g_dp.tb.ensure((size_t)n * slot))) return rc;
         if ((rc = g_dp.rows.ensure((size_t)n * row_cap * 4))) return rc;
         if ((rc = g_dp.ops.ensure((size_t)n * ops_cap * 4))) return rc;
+        if ((rc = g_dp.act.ensure((size_t)n * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
         for (u64 k = 0; k < n; k++) {
             LzDpJob& J = jobs[ids[k]];
             J.tb_off = k * (u64)slot; J.tb_cap = slot;
             J.row_off = k * (u64)row_cap; J.row_cap = row_cap;
             J.ops_off = k * (u64)ops_cap; J.ops_cap = ops_cap;
+            J.act_off = k * (u64)(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
         }
         if ((rc = g_dp.jobs.ensure(jobs.size() * sizeof(LzDpJob)))) return rc;
         if ((rc = g_dp.ids.ensure(n * 4))) return rc;
@@ -179,6 +181,7 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipMemcpyAsync(g_dp.jobs.p, jobs.data(), jobs.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
         LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.stream));
         P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
+        P.act_arena = g_dp.act.as<LzDpActive>();
         c.timer.begin("k_ydrop", c.stream);
         hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
                            S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());

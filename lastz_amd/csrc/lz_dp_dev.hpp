@@ -36,6 +36,7 @@
 #define LZ_UNROLL
 #endif
 #define LZ_DP_SERIAL_FILL 4           // overhang cells lane 0 stores itself at row end
+#define LZ_DP_ACT_LDS 32              // active segments kept in LDS (one more DP per CU than with all of them there)
 #define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
@@ -62,6 +63,7 @@ struct LzDpJob {
     u64 tb_off; u32 tb_cap;             // traceback bytes slot
     u64 row_off; u32 row_cap;           // tbRow[] slot (u32 per row)
     u64 ops_off; u32 ops_cap;           // edit ops slot (u32 each, traceback order)
+    u64 act_off;                        // overflow slot of the active-segment list (LZ_DP_MAXACT - LZ_DP_ACT_LDS entries)
 };
 
 struct LzDpResult {
@@ -78,6 +80,7 @@ struct LzDpParams {                     // per batch
     s32 gap_e, gap_oe, ydrop, ydrop_tail;
     u32 tb_len;                         // the REFERENCE's traceback size (truncation rule, :3640-3661)
     u8* tb_arena; u32* row_arena; u32* ops_arena;
+    struct LzDpActive* act_arena;
 };
 
 struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
@@ -98,7 +101,7 @@ struct LzDpShared {
     // traceback state
     u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
     u8  tb_win[64];
-    LzDpActive act[LZ_DP_MAXACT];
+    LzDpActive act[LZ_DP_ACT_LDS];        // the first active segments; the rest live in the job's HBM slot
 };
 
 // Sweep state of one DP.  Only lane 0 reads and writes it, so it lives in that lane's registers:
@@ -260,13 +263,15 @@ LZ_HD void lz_dp_peek_list(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJo
     c.next_act_row = x.uni(J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1));
 }
 
+LZ_HD LzDpActive& lz_dp_act(LzDpShared& sh, LzDpActive* spill, u32 k) { return k < LZ_DP_ACT_LDS ? sh.act[k] : spill[k - LZ_DP_ACT_LDS]; }
+
 // update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
 template <class X>
-LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J)
+LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive* spill)
 {
     const u32 row = c.row;
     for (u32 k = 0; k < c.n_act; k++) {
-        LzDpActive& act = sh.act[k];
+        LzDpActive& act = lz_dp_act(sh, spill, k);
         if (act.last_row >= row) {
             if (act.type == LZ_DIAG_SEG) act.x++;
             lz_dp_stamp(sh, c, act.x, row);
@@ -289,7 +294,7 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDp
         const s32* order = J.reversed ? S.oed : S.obi;
         const LzDpAlign& al = S.aligns[order[c.list_pos]];
         if (c.n_act >= LZ_DP_MAXACT) { c.status = LZ_DP_ACT_SLOT; c.done = 1; return; }
-        LzDpActive& act = sh.act[c.n_act++];
+        LzDpActive& act = lz_dp_act(sh, spill, c.n_act++);
         act.filter = 0; act.align = order[c.list_pos];
         act.seg = J.reversed ? al.last_seg : al.first_seg;
         lz_dp_build_active(S, sh, c, J, act);
@@ -297,7 +302,7 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDp
         lz_dp_peek_list(x, S, c, J);
     }
     u32 w = 0;                                                 // filter_active_segs(&active, 0)
-    for (u32 k = 0; k < c.n_act; k++) if (sh.act[k].filter == 0) { if (w != k) sh.act[w] = sh.act[k]; w++; }
+    for (u32 k = 0; k < c.n_act; k++) if (lz_dp_act(sh, spill, k).filter == 0) { if (w != k) lz_dp_act(sh, spill, w) = lz_dp_act(sh, spill, k); w++; }
     c.n_act = w;
 }
 
@@ -427,7 +432,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             ct.row++;
             ct.prevLY = ct.LY;
             lz_dp_update_lr(x, S, ct, J);
-            lz_dp_update_active(x, S, sh, ct, J);
+            lz_dp_update_active(x, S, sh, ct, J, P.act_arena + J.act_off);
             if (ct.done) return;
             if (ct.RY < ct.LY) ct.RY = ct.LY;                   // note 11
             const u32 width = ct.RY - ct.LY;

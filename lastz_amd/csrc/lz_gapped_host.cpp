@@ -276,7 +276,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // is therefore deferred: when the commit pass reaches it, it is either on a committed
     // alignment (skipped, as in the reference) or it starts the next window.  This only steers
     // what is speculated; what is committed is decided by the checks below.
-    const s64 NEAR_DIAG = 1500, NEAR_POS = 60000;
+    const s64 NEAR_DIAG = 1500, NEAR_POS = 60000, TIGHT_DIAG = 300;
+    const u32 INSURE = 256;
     u32 next = 0;
     std::vector<LzDpJob> jobs; std::vector<LzDpResult> res; std::vector<std::vector<u32>> ops;
     struct Entry { u32 anchor_ix; bool speculated; };
@@ -290,6 +291,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
         jobs.clear(); entries.clear(); chosen_grid.clear(); fresh.clear();
+        u32 insured = 0;
         u32 j = next;
         const u32 scan_limit = 64 * W;
         const size_t n_snap = S.aligns.size();
@@ -305,15 +307,22 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             // cell or one next to it -- a window scans up to 64 K anchors against up to 1 K selected ones)
             const s64 cell = (dg >= 0 ? dg : dg - (NEAR_DIAG - 1)) / NEAR_DIAG;
             if (hit == cache.end()) {
-                bool defer = false;
-                for (s64 cc = cell - 1; cc <= cell + 1 && !defer; cc++) {
+                // 0 = not near, 1 = near (loose), 2 = near and almost on the same diagonal (tight)
+                int near = 0;
+                for (s64 cc = cell - 1; cc <= cell + 1 && near < 2; cc++) {
                     auto g = chosen_grid.find(cc);
                     if (g == chosen_grid.end()) continue;
                     for (auto& c : g->second)
                         if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
-                            c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) { defer = true; break; }
+                            c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) {
+                            near = (c.first - dg <= TIGHT_DIAG && dg - c.first <= TIGHT_DIAG) ? 2 : (near < 1 ? 1 : near);
+                            if (near == 2) break;
+                        }
                 }
-                if (defer) { entries.push_back({ j, false }); continue; }
+                // a loosely near anchor is usually on the selected anchor's alignment too, but when it is not it
+                // costs a whole extra round for one DP: a bounded number of them is speculated anyway
+                if (near == 1 && insured < INSURE) { insured++; near = 0; }
+                if (near) { entries.push_back({ j, false }); continue; }
             }
             chosen_grid[cell].push_back({ dg, (s64)a1 });
             entries.push_back({ j, true });
@@ -334,6 +343,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             fresh.push_back(j);
         }
         lap(t_window);
+        if (prof && st.rounds >= 1) { fprintf(stderr, "[lzgpu hostprof] round %u speculates anchors (rank:score):", (unsigned)st.rounds + 1); for (size_t k = 0; k < fresh.size() && k < 12; k++) fprintf(stderr, " %u:%d", fresh[k], anchors[fresh[k]].s); fprintf(stderr, " of %u entries\n", (unsigned)entries.size()); }
         if (entries.empty()) { next = j; break; }
         if (!jobs.empty()) {
             res.assign(jobs.size(), LzDpResult());

@@ -52,9 +52,10 @@ struct EmulExec : LzDpExecutor {
                 std::vector<u8> tb(slot); std::vector<u32> rows(slot / 16 + 16), opbuf(slot / 4 + 16);
                 LzDpParams P; P.tdp = tdp.data() + LZ_SEQ_PAD; P.tlen = tlen; P.qdp = qdp.data() + LZ_SEQ_PAD; P.qlen = qlen;
                 P.gap_e = gap_e; P.gap_oe = gap_oe; P.ydrop = ydrop; P.ydrop_tail = ydrop / gap_e + 6; P.tb_len = tb_len;
-                P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data();
+                std::vector<LzDpActive> spill(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
+                P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data(); P.act_arena = spill.data();
                 LzDpJob& J = jobs[k];
-                J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size();
+                J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size(); J.act_off = 0;
                 CpuPhases x;
                 lz_dp_run(x, sh, S, P, J, tab, &res[k]);
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
