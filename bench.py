@@ -39,7 +39,9 @@ def pmc_traffic(kernel):
     gfx950 correction follow MI355X_MICROARCH.md: counters are in KiB; FETCH_SIZE under-reports wide
     reads by 2x (uncalibrated for 16-byte gathers: reported as measured x2 = upper bound)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v10 after r01_v9
     if not files:
         return None, None
     for line in open(files[-1]).read().split("\n")[1:]:
