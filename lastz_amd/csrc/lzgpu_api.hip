@@ -132,7 +132,7 @@ extern "C" int lzgpu_init(int device_index)
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_extended[k], hipEventDisableTiming));
     }
     LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_init, hipEventDisableTiming));
-    if (const char* hc = getenv("LZGPU_HIT_CAPACITY")) { const long long v = atoll(hc); if (v >= 1024) g_ctx.hit_capacity = (u64)v; }
+    if (const char* hc = getenv("LZGPU_HIT_CAPACITY")) { const long long v = atoll(hc); if (v >= 1024 && v <= (1ll << 31)) g_ctx.hit_capacity = (u64)v; }
     g_ctx.device = device_index;
     g_ctx.inited = true;
     return 0;
@@ -605,5 +605,9 @@ extern "C" int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, 
     if (total_ms) *total_ms = t.ms[n];
     return 0;
 }
-extern "C" int lzgpu_set_hit_capacity(uint64_t n) { if (n < 1024) return LZGPU_ERR_ARG; g_ctx.hit_capacity = n; return 0; }
+extern "C" int lzgpu_set_hit_capacity(uint64_t n)
+{
+    if (n < 1024 || n > (1ull << 31)) return LZGPU_ERR_ARG;     // hit indices inside a chunk are 32-bit
+    g_ctx.hit_capacity = n; return 0;
+}
 extern "C" int lzgpu_set_hsp_capacity(uint64_t n) { if (n < 16) return LZGPU_ERR_ARG; g_ctx.hsp_capacity = n; return 0; }
