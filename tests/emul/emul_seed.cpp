@@ -156,3 +156,55 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     return 0;
 }
 extern "C" void emul_free(void* p) { free(p); }
+
+// Self-test of the three block scanners on random class codes: the masked general scan
+// (lz_scan_left16/right16 without the 8x8 table), the whole-block byte scan and the 4-bit scan must agree
+// on (bases consumed, run, best) for every block, both directions.  Returns the number of mismatches.
+extern "C" int emul_scan_selftest(uint32_t seed, uint32_t rounds)
+{
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
+    s32 tab[LZ_NCLASS * LZ_NCLASS], tab8[64];
+    for (int i = 0; i < LZ_NCLASS * LZ_NCLASS; i++) tab[i] = (s32)(rnd() % 400) - 300;
+    for (int k = 0; k < 64; k++) tab8[k] = tab[(k >> 3) * LZ_NCLASS + (k & 7)];
+    int bad = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        std::vector<u8> t(256, 0), q(256, 0);
+        for (auto& b : t) b = (u8)((rnd() % 8) | ((rnd() % 4) << 5));
+        for (auto& b : q) b = (u8)((rnd() % 8) | ((rnd() % 4) << 5));
+        std::vector<u8> tn(200, 0), qn(200, 0);                 // LZ_SEQ_PAD nibbles of padding in front
+        for (size_t b = 0; b < 128; b++) { tn[LZ_SEQ_PAD / 2 + b] = (u8)((t[2 * b] & 7) | ((t[2 * b + 1] & 7) << 4)); qn[LZ_SEQ_PAD / 2 + b] = (u8)((q[2 * b] & 7) | ((q[2 * b + 1] & 7) << 4)); }
+        const s32 xd = (s32)(rnd() % 900) + 10;
+        const u32 pos = 64 + rnd() % 100;                       // block [pos-16,pos) to the left, [pos,pos+16) to the right
+        for (int right = 0; right < 2; right++) {
+            const s32 run0 = (s32)(rnd() % 500) - 100, best0 = run0 + (s32)(rnd() % 300);
+            u32 s1 = pos, s2 = pos; s32 r1 = run0, b1 = best0, r2 = run0, b2 = best0, r3 = run0, b3 = best0;
+            const LzVec16 tv = lz_load16(t.data() + (right ? pos : pos - 16)), qv = lz_load16(q.data() + (right ? pos : pos - 16));
+            bool a1, a2;
+            if (right) { a1 = lz_scan_right16(tab, nullptr, xd, tv, qv, 100000, s1, r1, b1); a2 = lz_scan_right16(tab, tab8, xd, tv, qv, 100000, s2, r2, b2); }
+            else       { a1 = lz_scan_left16(tab, nullptr, xd, tv, qv, -100000, s1, r1, b1); a2 = lz_scan_left16(tab, tab8, xd, tv, qv, -100000, s2, r2, b2); }
+            u32 nt[3], nq[3];
+            lz_load_nib<1>(tn.data(), right ? (s64)pos : (s64)pos - 16, nt);
+            lz_load_nib<1>(qn.data(), right ? (s64)pos : (s64)pos - 16, nq);
+            const u32 nok = right ? lz_scan16_nib<false>(tab8, xd, nt, nq, r3, b3) : lz_scan16_nib<true>(tab8, xd, nt, nq, r3, b3);
+            const u32 c3 = nok < 16 ? nok + 1 : 16, c1 = right ? s1 - pos : pos - s1, c2 = right ? s2 - pos : pos - s2;
+            if (c1 != c2 || c1 != c3 || b1 != b2 || b1 != b3 || a1 != a2 || a1 != (nok == 16)) bad++;
+            if (a1 && (r1 != r2 || r1 != r3)) bad++;            // run only matters while the scan goes on
+        }
+    }
+    return bad;
+}
+
+// lzh_sort4 (four-thread sort used by the host phases) against std::sort
+extern "C" int emul_sort4_selftest(uint32_t seed, uint32_t n)
+{
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 7;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    std::vector<std::pair<uint64_t, uint32_t>> a(n), b;
+    for (uint32_t i = 0; i < n; i++) a[i] = { rnd() % (n / 3 + 1), (uint32_t)(rnd() % 5) };   // many ties on the first key
+    b = a;
+    auto less = [](const std::pair<uint64_t, uint32_t>& p, const std::pair<uint64_t, uint32_t>& q) { return p < q; };
+    lzh_sort4(a.begin(), a.end(), less);
+    std::sort(b.begin(), b.end(), less);
+    return a == b ? 0 : 1;
+}

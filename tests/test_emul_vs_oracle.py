@@ -77,6 +77,25 @@ def test_matrix_with_more_than_8_classes(em):
     _check(em, t, q, masked=m, hsp_threshold=2200)
 
 
+def test_block_scanners_agree(em):
+    """masked byte scan == whole-block byte scan == 4-bit scan, block by block, on random codes"""
+    em.L.emul_scan_selftest.restype = C.c_int
+    assert em.L.emul_scan_selftest(C.c_uint32(12345), C.c_uint32(20000)) == 0
+
+
+def test_four_thread_sort(em):
+    em.L.emul_sort4_selftest.restype = C.c_int
+    for n in (10, 16384, 100003):
+        assert em.L.emul_sort4_selftest(C.c_uint32(n), C.c_uint32(n)) == 0
+
+
+def test_byte_code_path_without_nibbles(em, monkeypatch):
+    """the same searches with the 4-bit arrays switched off (the path a >= 8-class matrix takes for the windows)"""
+    monkeypatch.setenv("EMUL_NO_NIBBLES", "1")
+    t, q = H.load_case("synth200k")
+    _check(em, t, q, cap=20000)
+
+
 def test_chunk_planner_splits_inside_a_block(em):
     # a 9-mer exact seed on a low-complexity target: single query positions carry many hits
     rng = np.random.default_rng(5)
