@@ -160,6 +160,13 @@ LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
 #else
 #define LZ_CLOCK() ((u64)0)
 #endif
+// per-row step clocks (t_ph[], LZGPU_DPPROF): four s_memtime reads per row cost ~2-3 % of the sweep, so they
+// are compiled in only with -DLZ_DP_PHASE_CLOCKS; the two per-DP totals are always taken
+#if defined(LZ_DP_PHASE_CLOCKS)
+#define LZ_PHASE_CLOCK() LZ_CLOCK()
+#else
+#define LZ_PHASE_CLOCK() ((u64)0)
+#endif
 #define LZ_SDIFF(a, b) (((s32)(a)) - ((s32)(b)))
 #define LZ_RING(c) ((c) & (LZ_DP_MAXW - 1))
 
@@ -379,7 +386,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     bool swept = false;
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
     while (!sh.done) {
-        const u64 ts = LZ_CLOCK();
+        const u64 ts = LZ_PHASE_CLOCK();
         x.leader([&]() {
             [&]() {
             u32 extra = 0;
@@ -472,7 +479,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         // issued before the serial recurrence consumes them (one wave per SIMD has nothing else to
         // hide LDS latency behind).
         // walk 1: block summaries of the insertion recurrence
-        const u64 ta = LZ_CLOCK();
+        const u64 ta = LZ_PHASE_CLOCK();
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
@@ -506,7 +513,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
         i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
-        const u64 tb_ = LZ_CLOCK();
+        const u64 tb_ = LZ_PHASE_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
@@ -554,7 +561,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         });
         // 64-lane exclusive prefix max of the candidates, seeded with bestScore at row start
         x.scan_cand(sh, best0);
-        const u64 tc = LZ_CLOCK();
+        const u64 tc = LZ_PHASE_CLOCK();
         // walk 3: prune test against the running best, final stores, traceback bytes
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
@@ -586,7 +593,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             r.first = first; r.last = last;
         });
         x.reduce_row(sh);
-        const u64 td = LZ_CLOCK();
+        const u64 td = LZ_PHASE_CLOCK();
         tp0 += ta - ts; tp1 += tb_ - ta; tp2 += tc - tb_; tp3 += td - tc;
     }
 
