@@ -51,7 +51,7 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(t, q, qlen_bench, sample_bp):
+def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False):
     """The pristine reference (oracle/_ref/lastz_stats, built from /root/reference in the build
     container and shipped with the snapshot) on a bounded sample of the same workload, 1 core
     (lastz is single-threaded).  Falls back to the oracle port if the binary is absent."""
@@ -64,8 +64,15 @@ def cpu_baseline(t, q, qlen_bench, sample_bp):
             tf, qf, st = os.path.join(d, "t.fa"), os.path.join(d, "q.fa"), os.path.join(d, "st.txt")
             seqio.write_fasta(tf, [("target", ts)]); seqio.write_fasta(qf, [("query", qs)])
             t0 = time.time()
-            p = subprocess.run([ref, tf, qf, "--nogapped", "--stats=" + st], stdout=subprocess.DEVNULL,
-                               stderr=subprocess.PIPE, text=True)
+            # with --gapped the same run also yields the DP stage's clock and cell count (the table and search
+            # clocks do not depend on what follows them)
+            p = subprocess.run([ref, tf, qf, "--ydrop=9430" if gapped else "--nogapped", "--stats=" + st],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            dp_cells = None
+            if gapped and os.path.exists(st):
+                for line in open(st):
+                    if "DP cells visited" in line:
+                        dp_cells = int(line.split(":")[1].replace(",", ""))
             wall = time.time() - t0
             clocks = {}
             for line in p.stderr.split("\n"):
@@ -81,6 +88,9 @@ def cpu_baseline(t, q, qlen_bench, sample_bp):
         kind = "reference"
         detail = {"seed_position_table_s": clocks.get("seed position table"),
                   "seed_hit_search_s": clocks.get("seed hit search"), "process_wall_s": round(wall, 3)}
+        if gapped and dp_cells and clocks.get("gapped extension"):
+            detail["gapped"] = {"dp_cells": dp_cells, "gapped_extension_s": clocks["gapped extension"],
+                                "gcups": dp_cells / clocks["gapped extension"] / 1e9, "cores": 1}
     else:
         from oracle import lzo
         _, masked = lzo.hoxd70_scoring()
@@ -96,7 +106,8 @@ def cpu_baseline(t, q, qlen_bench, sample_bp):
     value = rate_bp2 / (2.0 * qlen_bench) / 1e9
     return {"value": value, "unit": "Gbp/s", "cores": 1, "kind": kind,
             "sample": f"first {len(ts)} bp of target x first {len(qs)} bp of query, both strands, "
-                      f"--nogapped ({sec:.2f} s of table+search CPU time); scaled by Tlen*Qlen to the bench query size",
+                      f"{'--ydrop=9430 run, seed-stage clocks' if gapped else '--nogapped'} ({sec:.2f} s of table+search CPU time); "
+                      f"scaled by Tlen*Qlen to the bench query size",
             "bp2_per_s": rate_bp2, **detail}
 
 
@@ -336,7 +347,10 @@ def main():
         if gapped is not None:
             out["gapped"] = gapped
         if world == 1 and not a.no_cpu_baseline:
-            cb = cpu_baseline(target, q0, a.qlen, min(a.cpu_sample, a.tlen, a.qlen))
+            cb = cpu_baseline(target, q0, a.qlen, min(a.cpu_sample, a.tlen, a.qlen), gapped=a.gapped)
+            if gapped is not None and "gapped" in cb:
+                gapped["cpu_baseline"] = cb.pop("gapped")
+                gapped["speedup_vs_cpu_1core"] = gapped["gcups_wall"] / gapped["cpu_baseline"]["gcups"]
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1core"] = value / cb["value"] if cb["value"] else None
         print(json.dumps(out))
