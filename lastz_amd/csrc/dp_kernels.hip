@@ -1,4 +1,4 @@
-// dp_kernels.hip -- B3 on gfx950: the Y-drop one-sided DP kernel (one wave per DP, sweep row in
+// dp_kernels.hip -- B3 on gfx950: the Y-drop one-sided DP kernel (four waves per DP, sweep row in
 // LDS, traceback bytes in HBM), the HIP executor that feeds it batches of speculative DPs, and the
 // lzgpu_gapped_extend entry point.  The algorithm itself is in lz_dp_dev.hpp (shared with the
 // CPU phase emulator used by the no-GPU tests); the anchor ordering / commit logic is in

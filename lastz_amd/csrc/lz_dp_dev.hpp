@@ -1,12 +1,18 @@
 // lz_dp_dev.hpp -- the Y-drop gapped extension (ydrop_one_sided_align, src/gapped_extend.c:3388-3868)
-// as ONE WAVE PER ONE-SIDED DP, written once for the device and for the host test harness.
+// as ONE WORKGROUP OF LZ_DP_LANES LANES PER ONE-SIDED DP, written once for the device and for the host
+// test harness.
 //
-// Execution model.  lz_dp_run() is a sequence of PHASES.  A phase is a piece of per-lane code
-// (lane = 0..63) that only communicates with other lanes through the LzDpShared block; phases
-// are separated by barriers.  On the GPU, X::phase(f) runs f(lane) for the calling thread and
-// then __syncthreads() (one wave per workgroup, LzDpShared in LDS).  In tests/emul, X::phase(f)
-// runs f for lane 0..63 in turn.  Control flow between phases only depends on LzDpShared fields
-// written in an earlier phase, so it is wave-uniform by construction.
+// Execution model.  lz_dp_run() is a sequence of steps over the lanes 0..LZ_DP_LANES-1, which only
+// communicate through the LzDpShared block (LDS on the GPU) and through the executor's cross-lane
+// steps.  The executor X supplies:
+//   X::phase(f)   f(lane) on every lane, then a barrier;
+//   X::step(f)    the same without a barrier (f touches registers and the lane's own LDS cells only);
+//   X::leader(f)  a serial piece, once per DP, then a barrier (on the GPU: one whole wave in lockstep,
+//                 its inputs passed through X::uni so that the sweep state LzDpCtl stays scalar);
+//   X::scan_gap / scan_cand / reduce_row / row_result   the cross-lane steps (DPP scans + LDS partials
+//                 on the GPU, plain loops in tests/emul).
+// Control flow between steps only depends on values every lane reads from LzDpShared after a barrier,
+// so it is uniform by construction.
 //
 // Row algorithm.  The reference sweeps a row left to right with three
 // loop-carried values: the insertion score i, the running bestScore (for the Y-drop test) and the
@@ -18,10 +24,10 @@
 //   * the running bestScore before column c is max(best_at_row_start, max of diagonal-won cells
 //     left of c): a plain prefix max, because a cell that raises the best is never pruned.
 //   * LY advances over the leading pruned cells: LY' = first live column.
-// So a row is: walk 1 (per-lane block summaries of the i-recurrence) -> 64-lane scan -> walk 2
-// (cells, links, candidate bests) -> 64-lane prefix max -> walk 3 (prune test, stores,
-// traceback bytes) -> row end (right bound, overhang of insertions, :3786-3827).
-// Lane l owns cpl = ceil(width/64) consecutive columns of the row.
+// So a row is: leader step (row end of the previous row, :3786-3827, + bounds / masks / traceback budget
+// of this one) -> walk 1 (per-lane block summaries of the i-recurrence) -> scan -> walk 2 (cells, links,
+// candidate bests) -> prefix max -> walk 3 (prune test, stores, traceback bytes) -> row reduction.
+// Lane l owns cpl = ceil(width/LZ_DP_LANES) consecutive columns of the row.
 #pragma once
 #include "lz_common.hpp"
 

@@ -4,9 +4,10 @@
 // Decomposition: the only cross-hit state of the reference's HSP search is
 // diagEnd[hashedDiag] (src/seed_search.c:1081-1126, 2612-2616, 2785-2789), so the exact
 // parallel form is 65,536 independent, order-preserving streams.  Hits are enumerated in the
-// reference's order (count -> scan -> fill gives every hit its discovery index), stably
-// partitioned by the 16 hash bits (LSD radix sort restricted to key bits 32..47), and each
-// bucket is then walked by one lane with diagEnd[h] in a register.
+// reference's order (count -> scan -> fill gives every hit its discovery index; the table itself
+// is probed in seed-word order), scanned independently of the hash (phase A, k_probe_hits), stably
+// partitioned by the 16 hash bits (LSD radix sort restricted to key bits 32..47), and each bucket
+// is then walked by one lane with diagEnd[h] in a register (phase B, k_extend).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
