@@ -272,21 +272,42 @@ LZ_HD bool lz_scan_right16(const s32* score_tab, const s32* tab8, s32 xd, const 
 #endif
 // 4-bit codes: nibble n of the array is base n - LZ_SEQ_PAD.  `cnt` dwords (8 bases each) starting AT
 // base `base` (any parity): whole 16-byte loads from the byte that holds it, then a 4-bit funnel shift.
+// (LZ_PIN keeps the compiler from splitting the 16-byte loads into per-use dword loads sunk into the
+// blocks that need them: the point is to have the whole window in flight at once)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LZ_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define LZ_PIN(x) ((void)0)
+#endif
 template <int NLOAD>
-LZ_HD void lz_load_nib(const u8* nib, s64 base, u32* out /*[4*NLOAD - 1]*/)
+LZ_HD u32 lz_nib_issue(const u8* nib, s64 base, u32* raw /*[4*NLOAD]*/)      // the loads; returns the funnel shift
 {
     const s64 n = base + LZ_SEQ_PAD;
     const u8* p = nib + (n >> 1);
-    const u32 sh = (u32)(n & 1) * 4u;
-    u32 raw[4 * NLOAD];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < NLOAD; k++) { const LzVec16 v = lz_load16(p + 16 * k); raw[4 * k] = v.w[0]; raw[4 * k + 1] = v.w[1]; raw[4 * k + 2] = v.w[2]; raw[4 * k + 3] = v.w[3]; }
+    return (u32)(n & 1) * 4u;
+}
+template <int NLOAD>
+LZ_HD void lz_nib_finish(u32* raw /*[4*NLOAD]*/, u32 sh, u32* out /*[4*NLOAD - 1]*/)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4 * NLOAD; j++) LZ_PIN(raw[j]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int j = 0; j < 4 * NLOAD - 1; j++) out[j] = (u32)(((((u64)raw[j + 1]) << 32) | raw[j]) >> sh);
+}
+template <int NLOAD>
+LZ_HD void lz_load_nib(const u8* nib, s64 base, u32* out /*[4*NLOAD - 1]*/)
+{
+    u32 raw[4 * NLOAD];
+    const u32 sh = lz_nib_issue<NLOAD>(nib, base, raw);
+    lz_nib_finish<NLOAD>(raw, sh, out);
 }
 
 #define LZ_PROBE_NLOAD ((16 * (LZ_PROBE_AHEAD_L + LZ_PROBE_AHEAD_R) + 1 + 31) / 32)   // 16-byte loads covering the window at either parity
@@ -307,9 +328,11 @@ LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s3
     st.alive_r = ((s32)st.sr < st.stopr) && (0 >= -xd);
     if (tab8 && P.tnib && xd >= 0 && (s32)pos1 - st.stopl >= 16 * LZ_PROBE_AHEAD_L && st.stopr - (s32)pos1 >= 16 * LZ_PROBE_AHEAD_R) {
         // every block of the window is a whole one: LZ_PROBE_NLOAD 16-byte loads per sequence
-        u32 tw[4 * LZ_PROBE_NLOAD - 1], qw[4 * LZ_PROBE_NLOAD - 1];
-        lz_load_nib<LZ_PROBE_NLOAD>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, tw);
-        lz_load_nib<LZ_PROBE_NLOAD>(P.qnib, (s64)pos2 - 16 * LZ_PROBE_AHEAD_L, qw);
+        u32 tw[4 * LZ_PROBE_NLOAD - 1], qw[4 * LZ_PROBE_NLOAD - 1], traw[4 * LZ_PROBE_NLOAD], qraw[4 * LZ_PROBE_NLOAD];
+        const u32 tsh = lz_nib_issue<LZ_PROBE_NLOAD>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, traw);
+        const u32 qsh = lz_nib_issue<LZ_PROBE_NLOAD>(P.qnib, (s64)pos2 - 16 * LZ_PROBE_AHEAD_L, qraw);
+        lz_nib_finish<LZ_PROBE_NLOAD>(traw, tsh, tw);
+        lz_nib_finish<LZ_PROBE_NLOAD>(qraw, qsh, qw);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -360,8 +383,10 @@ LZ_HD bool lz_scan_continue(const LzExtendParams& P, const s32* score_tab, const
         if (tab8 && P.tnib && room >= 16u && P.xdrop >= 0) {
             u32 tn[3], qn[3];
             const s64 b1 = RIGHT ? (s64)s : (s64)s - 16;
-            lz_load_nib<1>(P.tnib, b1, tn);
-            lz_load_nib<1>(P.qnib, b1 - diag, qn);
+            u32 traw[4], qraw[4];
+            const u32 tsh = lz_nib_issue<1>(P.tnib, b1, traw), qsh = lz_nib_issue<1>(P.qnib, b1 - diag, qraw);
+            lz_nib_finish<1>(traw, tsh, tn);
+            lz_nib_finish<1>(qraw, qsh, qn);
             const u32 nok = lz_scan16_nib<!RIGHT>(tab8, P.xdrop, tn, qn, run, best);
             const u32 c = nok < 16u ? nok + 1u : 16u;
             s = RIGHT ? s + c : s - c;
