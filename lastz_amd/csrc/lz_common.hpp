@@ -135,6 +135,8 @@ LZ_HD LzVec16 lz_load16(const u8* p) { LzVec16 v; __builtin_memcpy(&v, p, 16); r
 #define LZ_SUMM_DEXT(s) (((s) >> 8) & 0xFFu)  // extent - pos2 (bases the right scan consumed)
 
 // A whole block in one go, for the common case (>= 16 bases of room, < 8 scoring classes).
+// (tab8 is always the table's address and `fast` the switch, so that on the device the LDS address of the
+// table is a constant the look-ups fold into their offset field: one VALU add less per base.)
 // - score look-up: (row class << 5 | column class << 2) IS the byte address in an 8 x 8 table,
 //   built four bases at a time; with 8 words per row the 16 ACGT pairs fall into 16 LDS banks.
 // - X-drop chain without masks: a base passes if run >= best - xDrop (the test of the reference
@@ -211,11 +213,11 @@ LZ_HD u32 lz_scan16_nib(const s32* tab8, s32 xd, const u32 tn[2], const u32 qn[2
 // One 16-base block of the left scan (loop 1, :2623-2632: bases sl-1, sl-2, ... taken from the
 // 16 bytes that END at sl) and of the right scan (loop 2, :2684-2693: the 16 bytes that START at sr).
 // "run >= best - xDrop" gates each further base; the return value says whether the scan goes on.
-LZ_HD bool lz_scan_left16(const s32* score_tab, const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv,
+LZ_HD bool lz_scan_left16(const s32* score_tab, const s32* tab8, bool fast, s32 xd, const LzVec16& tv, const LzVec16& qv,
                           s32 stopl, u32& sl, s32& runl, s32& bestl)
 {
     const u32 room = (u32)((s32)sl - stopl);
-    if (tab8 && room >= 16u && xd >= 0) {
+    if (fast && room >= 16u && xd >= 0) {
         const u32 nok = lz_scan16_fast<true>(tab8, xd, tv, qv, runl, bestl);
         sl -= (nok < 16u) ? nok + 1u : 16u;
         return nok == 16u && (s32)sl > stopl;
@@ -234,11 +236,11 @@ LZ_HD bool lz_scan_left16(const s32* score_tab, const s32* tab8, s32 xd, const L
         if (go && (u32)k < room) { runl += sc[k]; --sl; if (runl > bestl) bestl = runl; go = runl >= bestl - xd; }
     return go && ((s32)sl > stopl);
 }
-LZ_HD bool lz_scan_right16(const s32* score_tab, const s32* tab8, s32 xd, const LzVec16& tv, const LzVec16& qv,
+LZ_HD bool lz_scan_right16(const s32* score_tab, const s32* tab8, bool fast, s32 xd, const LzVec16& tv, const LzVec16& qv,
                            s32 stopr, u32& sr, s32& runr, s32& bestr)
 {
     const u32 room = (u32)(stopr - (s32)sr);
-    if (tab8 && room >= 16u && xd >= 0) {
+    if (fast && room >= 16u && xd >= 0) {
         const u32 nok = lz_scan16_fast<false>(tab8, xd, tv, qv, runr, bestr);
         sr += (nok < 16u) ? nok + 1u : 16u;
         return nok == 16u && (s32)sr < stopr;
@@ -313,7 +315,7 @@ LZ_HD void lz_load_nib(const u8* nib, s64 base, u32* out /*[4*NLOAD - 1]*/)
 #define LZ_PROBE_NLOAD ((16 * (LZ_PROBE_AHEAD_L + LZ_PROBE_AHEAD_R) + 1 + 31) / 32)   // 16-byte loads covering the window at either parity
 struct LzProbeSt { u32 pos1; s32 diag, stopl, stopr; u32 sl, sr; s32 runl, bestl, runr, bestr; bool alive_l, alive_r; };
 
-LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key, LzProbeSt& st)
+LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8, used if fast*/, bool fast, u64 key, LzProbeSt& st)
 {
     const s32 xd = P.xdrop;
     const u32 pos2 = (u32)key;
@@ -326,7 +328,7 @@ LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s3
     st.runl = st.bestl = st.runr = st.bestr = 0;
     st.alive_l = ((s32)st.sl > st.stopl) && (0 >= -xd);
     st.alive_r = ((s32)st.sr < st.stopr) && (0 >= -xd);
-    if (tab8 && P.tnib && xd >= 0 && (s32)pos1 - st.stopl >= 16 * LZ_PROBE_AHEAD_L && st.stopr - (s32)pos1 >= 16 * LZ_PROBE_AHEAD_R) {
+    if (fast && P.tnib && xd >= 0 && (s32)pos1 - st.stopl >= 16 * LZ_PROBE_AHEAD_L && st.stopr - (s32)pos1 >= 16 * LZ_PROBE_AHEAD_R) {
         // every block of the window is a whole one: LZ_PROBE_NLOAD 16-byte loads per sequence
         u32 tw[4 * LZ_PROBE_NLOAD - 1], qw[4 * LZ_PROBE_NLOAD - 1], traw[4 * LZ_PROBE_NLOAD], qraw[4 * LZ_PROBE_NLOAD];
         const u32 tsh = lz_nib_issue<LZ_PROBE_NLOAD>(P.tnib, (s64)pos1 - 16 * LZ_PROBE_AHEAD_L, traw);
@@ -367,20 +369,20 @@ LZ_HD void lz_probe_head(const LzExtendParams& P, const s32* score_tab, const s3
 #pragma unroll
 #endif
     for (int b = 0; b < LZ_PROBE_AHEAD_L; b++) {
-        if (st.alive_l) st.alive_l = lz_scan_left16(score_tab, tab8, xd, tl[b], ql[b], st.stopl, st.sl, st.runl, st.bestl);
-        if (b < LZ_PROBE_AHEAD_R && st.alive_r) st.alive_r = lz_scan_right16(score_tab, tab8, xd, tr[b], qr[b], st.stopr, st.sr, st.runr, st.bestr);
+        if (st.alive_l) st.alive_l = lz_scan_left16(score_tab, tab8, fast, xd, tl[b], ql[b], st.stopl, st.sl, st.runl, st.bestl);
+        if (b < LZ_PROBE_AHEAD_R && st.alive_r) st.alive_r = lz_scan_right16(score_tab, tab8, fast, xd, tr[b], qr[b], st.stopr, st.sr, st.runr, st.bestr);
     }
 }
 
 // continue one scan for at most `blocks` further blocks; returns whether it is still alive (at the cap)
 template <bool RIGHT>
-LZ_HD bool lz_scan_continue(const LzExtendParams& P, const s32* score_tab, const s32* tab8, s32 diag, s32 stop,
+LZ_HD bool lz_scan_continue(const LzExtendParams& P, const s32* score_tab, const s32* tab8, bool fast, s32 diag, s32 stop,
                             u32& s, s32& run, s32& best, int blocks)
 {
     bool alive = true;
     for (; blocks > 0 && alive; blocks--) {
         const u32 room = RIGHT ? (u32)(stop - (s32)s) : (u32)((s32)s - stop);
-        if (tab8 && P.tnib && room >= 16u && P.xdrop >= 0) {
+        if (fast && P.tnib && room >= 16u && P.xdrop >= 0) {
             u32 tn[3], qn[3];
             const s64 b1 = RIGHT ? (s64)s : (s64)s - 16;
             u32 traw[4], qraw[4];
@@ -393,8 +395,8 @@ LZ_HD bool lz_scan_continue(const LzExtendParams& P, const s32* score_tab, const
             alive = nok == 16u && (RIGHT ? (s32)s < stop : (s32)s > stop);
             continue;
         }
-        if (RIGHT) alive = lz_scan_right16(score_tab, tab8, P.xdrop, lz_load16(P.tcode + s), lz_load16(P.qcode + ((s32)s - diag)), stop, s, run, best);
-        else       alive = lz_scan_left16(score_tab, tab8, P.xdrop, lz_load16(P.tcode + s - 16), lz_load16(P.qcode + ((s32)s - diag) - 16), stop, s, run, best);
+        if (RIGHT) alive = lz_scan_right16(score_tab, tab8, fast, P.xdrop, lz_load16(P.tcode + s), lz_load16(P.qcode + ((s32)s - diag)), stop, s, run, best);
+        else       alive = lz_scan_left16(score_tab, tab8, fast, P.xdrop, lz_load16(P.tcode + s - 16), lz_load16(P.qcode + ((s32)s - diag) - 16), stop, s, run, best);
     }
     return alive;
 }
@@ -406,12 +408,12 @@ LZ_HD u32 lz_probe_summary(const LzExtendParams& P, const LzProbeSt& st)
     return summ;
 }
 
-LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8 or NULL*/, u64 key)
+LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32* tab8 /*8x8, used if fast*/, bool fast, u64 key)
 {
     LzProbeSt st;
-    lz_probe_head(P, score_tab, tab8, key, st);
-    if (st.alive_l) st.alive_l = lz_scan_continue<false>(P, score_tab, tab8, st.diag, st.stopl, st.sl, st.runl, st.bestl, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
-    if (st.alive_r) st.alive_r = lz_scan_continue<true>(P, score_tab, tab8, st.diag, st.stopr, st.sr, st.runr, st.bestr, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
+    lz_probe_head(P, score_tab, tab8, fast, key, st);
+    if (st.alive_l) st.alive_l = lz_scan_continue<false>(P, score_tab, tab8, fast, st.diag, st.stopl, st.sl, st.runl, st.bestl, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
+    if (st.alive_r) st.alive_r = lz_scan_continue<true>(P, score_tab, tab8, fast, st.diag, st.stopr, st.sr, st.runr, st.bestr, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
     return lz_probe_summary(P, st);
 }
 

@@ -368,11 +368,11 @@ k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* _
     if (threadIdx.x < 64) tab8[threadIdx.x] = score_tab_g[(threadIdx.x >> 3) * LZ_NCLASS + (threadIdx.x & 7)];
     if (threadIdx.x == 0) { n_left = 0; n_right = 0; }
     __syncthreads();
-    const s32* t8 = P.cls8 ? tab8 : nullptr;
+    const bool fast = P.cls8 != 0;
     const u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
     LzProbeSt st;
     st.alive_l = st.alive_r = false;
-    if (i < n) lz_probe_head(P, tab, t8, keys[i], st);
+    if (i < n) lz_probe_head(P, tab, tab8, fast, keys[i], st);
     int slot_l = -1, slot_r = -1;
     if (st.alive_l) {
         slot_l = (int)atomicAdd(&n_left, 1u);
@@ -388,8 +388,8 @@ k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* _
         LzScanTask& q = task[k < nl ? k : 2 * LZ_TPB - 1 - (k - nl)];
         u32 s = q.s; s32 run = q.run, best = q.best;
         bool alive;
-        if (q.side) alive = lz_scan_continue<true>(P, tab, t8, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
-        else        alive = lz_scan_continue<false>(P, tab, t8, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
+        if (q.side) alive = lz_scan_continue<true>(P, tab, tab8, fast, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
+        else        alive = lz_scan_continue<false>(P, tab, tab8, fast, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
         q.s = s; q.best = best; q.run = alive ? 1 : 0;          // the result goes back through the task's slot
     }
     __syncthreads();

@@ -124,7 +124,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         if (!a->extend) { for (u64 k : keys) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); } continue; }
         // phase A on the unsorted hits, then the (key, summary) pairs are partitioned together
         std::vector<std::pair<u64, u32>> kv(keys.size());
-        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, P.cls8 ? tab8 : nullptr, keys[i]) };
+        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]) };
         std::stable_sort(kv.begin(), kv.end(), [](auto& x, auto& y) { return ((x.first >> 32) & 0xFFFF) < ((y.first >> 32) & 0xFFFF); });
         std::vector<u32> summ(keys.size());
         for (size_t i = 0; i < keys.size(); i++) { keys[i] = kv[i].first; summ[i] = kv[i].second; }
@@ -181,8 +181,8 @@ extern "C" int emul_scan_selftest(uint32_t seed, uint32_t rounds)
             u32 s1 = pos, s2 = pos; s32 r1 = run0, b1 = best0, r2 = run0, b2 = best0, r3 = run0, b3 = best0;
             const LzVec16 tv = lz_load16(t.data() + (right ? pos : pos - 16)), qv = lz_load16(q.data() + (right ? pos : pos - 16));
             bool a1, a2;
-            if (right) { a1 = lz_scan_right16(tab, nullptr, xd, tv, qv, 100000, s1, r1, b1); a2 = lz_scan_right16(tab, tab8, xd, tv, qv, 100000, s2, r2, b2); }
-            else       { a1 = lz_scan_left16(tab, nullptr, xd, tv, qv, -100000, s1, r1, b1); a2 = lz_scan_left16(tab, tab8, xd, tv, qv, -100000, s2, r2, b2); }
+            if (right) { a1 = lz_scan_right16(tab, tab8, false, xd, tv, qv, 100000, s1, r1, b1); a2 = lz_scan_right16(tab, tab8, true, xd, tv, qv, 100000, s2, r2, b2); }
+            else       { a1 = lz_scan_left16(tab, tab8, false, xd, tv, qv, -100000, s1, r1, b1); a2 = lz_scan_left16(tab, tab8, true, xd, tv, qv, -100000, s2, r2, b2); }
             u32 nt[3], nq[3];
             lz_load_nib<1>(tn.data(), right ? (s64)pos : (s64)pos - 16, nt);
             lz_load_nib<1>(qn.data(), right ? (s64)pos : (s64)pos - 16, nq);
