@@ -212,6 +212,17 @@ int lzgpu_set_hsp_capacity(uint64_t max_candidate_hsps);
 int lzgpu_set_dp_slot(uint32_t first_try_traceback_bytes_per_dp);
 int lzgpu_set_dp_window(uint32_t max_anchors_speculated_per_round);
 
+/* Sharding INSIDE one query (exact alternative (1) for the HSP stage): the only cross-hit state of
+ * seed_hit_search is diagEnd[hashedDiag] (src/diag_hash.h:61-64), so the 65,536 buckets can be dealt out to
+ * n_owners processes: every process enumerates the table probes, but materialises, scans and extends only
+ * the hits whose bucket b satisfies b % n_owners == owner.  The HSPs a process returns are those of its
+ * buckets, in discovery order among themselves; lzgpu_last_hsp_order gives, for the HSPs of the LAST search,
+ * two sort words each (query position << 32 | probe index, then ~target position): merging the processes'
+ * lists by them reproduces the single-process list exactly.  Counters: raw_hits / extensions / bp_extended /
+ * hsps are partitioned, words is replicated.  Default (1, 0) = everything. */
+int lzgpu_set_bucket_owner(uint32_t n_owners, uint32_t owner);
+int lzgpu_last_hsp_order(uint64_t* out /* [2 * n] */, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif

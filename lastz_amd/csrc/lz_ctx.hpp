@@ -79,6 +79,8 @@ struct LzCtx {
     DevBuf hsp_mc;                  // [n][5]: A/C/G/T match counts of the candidates (entropy inputs) + probe index
     DevBuf dev_counters;            // u64[8]
     DevBuf tb_keys, tb_vals, tb_keys2, tb_vals2;   // table build scratch
+    u32 n_owners = 1, owner = 0;      // bucket ownership (lzgpu_set_bucket_owner)
+    std::vector<u64> last_order;      // two sort words per HSP of the last search
     u64 hit_capacity = (1ull << 28);
     u64 hsp_capacity = (1ull << 24);
 
@@ -96,7 +98,7 @@ int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev)
 int lzk_pack_nibbles(LzCtx& c, const u8* code_alloc, u8* nib, size_t nbytes);
 int lzk_table_build(LzCtx& c);
 int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
-int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);
+int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);   // honours c.n_owners / c.owner
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out);
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys);

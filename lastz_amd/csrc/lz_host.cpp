@@ -156,9 +156,10 @@ struct RecKey { u64 hi; u32 lo, idx; };       // hi = pos2 << 32 | probe, lo = ~
 
 int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
-                    std::vector<lz_hsp>& out, const u32* match_counts)
+                    std::vector<lz_hsp>& out, const u32* match_counts, std::vector<u64>* order_out)
 {
     out.clear();
+    if (order_out) order_out->clear();
     std::vector<RecKey> order(n_rec);
     for (u32 i = 0; i < n_rec; i++) {
         u32 pt = 0, pq = 0, probe = 0;
@@ -212,6 +213,7 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
         const LzHspRec& r = recs[order[k].idx];
         const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
         out.push_back({ r.end1, (u32)((s32)r.end1 - diag), r.length, sims[k] });
+        if (order_out) { order_out->push_back(order[k].hi); order_out->push_back((u64)order[k].lo); }
     }
     return 0;
 }

@@ -55,7 +55,7 @@ int lzh_plan_chunks(u32 n, u64 cap, u32 S, OffAt&& off_at, std::vector<LzChunk>&
 // both are derived here from thost/qhost.
 int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* qhost,
                     const LzSeedDev& sd, const int8_t ctb[256], s32 K, int entropic,
-                    std::vector<lz_hsp>& out, const u32* match_counts = nullptr);
+                    std::vector<lz_hsp>& out, const u32* match_counts, std::vector<u64>* order_out = nullptr);
 double lzh_entropy_from_counts(int cA, int cC, int cG, int cT, int len);
 
 // std::sort on four threads (quarters, then two merges) for the host phases during which the GPU

@@ -579,7 +579,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     g_hp.lap(5, "copy candidates");
     std::vector<lz_hsp> fin;
     if ((rc = lzh_finish_hsps(recs.data(), n_rec, c.target.host.data(), qhost, c.seed, c.geom.char_to_bits,
-                              a->hsp_threshold, a->entropic, fin, gpu_counts ? mc.data() : nullptr)))
+                              a->hsp_threshold, a->entropic, fin, gpu_counts ? mc.data() : nullptr, &c.last_order)))
         return lz_fail(rc, "internal: candidate HSP is not on a seed hit");
     lz_hsp* res = (lz_hsp*)malloc((fin.size() ? fin.size() : 1) * sizeof(lz_hsp));
     if (!res) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
@@ -609,5 +609,17 @@ extern "C" int lzgpu_set_hit_capacity(uint64_t n)
 {
     if (n < 1024 || n > (1ull << 31)) return LZGPU_ERR_ARG;     // hit indices inside a chunk are 32-bit
     g_ctx.hit_capacity = n; return 0;
+}
+extern "C" int lzgpu_set_bucket_owner(uint32_t n_owners, uint32_t owner)
+{
+    if (n_owners < 1 || n_owners > LZ_DIAG_SIZE || owner >= n_owners) return LZGPU_ERR_ARG;
+    g_ctx.n_owners = n_owners; g_ctx.owner = owner;
+    return 0;
+}
+extern "C" int lzgpu_last_hsp_order(uint64_t* out, uint64_t n)
+{
+    if (!out || 2 * n != g_ctx.last_order.size()) return LZGPU_ERR_ARG;
+    memcpy(out, g_ctx.last_order.data(), g_ctx.last_order.size() * 8);
+    return 0;
 }
 extern "C" int lzgpu_set_hsp_capacity(uint64_t n) { if (n < 16) return LZGPU_ERR_ARG; g_ctx.hsp_capacity = n; return 0; }

@@ -225,6 +225,29 @@ k_count_sorted(const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, Lz
     cnt[sv[j]] = c;
 }
 
+// bucket ownership (lzgpu_set_bucket_owner): only the hits whose hashed diagonal belongs to this process
+// count; that needs the positions, so the lists are read here as well (front to back, like the fill)
+__device__ __forceinline__ bool lz_owned(u32 pos1, u32 pos2, u32 n_owners, u32 owner)
+{ return (((pos1 - pos2) & (LZ_DIAG_SIZE - 1)) % n_owners) == owner; }
+
+__global__ void __launch_bounds__(LZ_TPB)
+k_count_sorted_owned(const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, u32 lo, LzSeedDev sd,
+                     const u32* __restrict__ wstart, const u32* __restrict__ wpos, u32* __restrict__ cnt,
+                     u32 n_owners, u32 owner)
+{
+    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (j >= n) return;
+    const u32 w0 = sk[j];
+    if (w0 >> sd.weight) return;
+    const u32 i = sv[j], pos2 = lo + i + 1;
+    u32 c = 0;
+    for (int p = 0; p < sd.nprobes; p++) {
+        const u32 w = w0 ^ sd.probe_xor[p];
+        for (u32 k = wstart[w]; k < wstart[w + 1]; k++) c += lz_owned(wpos[k], pos2, n_owners, owner) ? 1u : 0u;
+    }
+    cnt[i] = c;
+}
+
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev)
 {
     const u32 n = hi - lo;
@@ -244,8 +267,12 @@ int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk,
     c.timer.end(c.stream);
     hipLaunchKernelGGL(k_count_words, dim3(1), dim3(1), 0, c.stream, sk, n, 1u << c.seed.weight, valid_words_dev);
     c.timer.begin("k_count_hits", c.stream);
-    hipLaunchKernelGGL(k_count_sorted, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
-                       sk, sv, n, c.seed, c.wstart.as<u32>(), cnt);
+    if (c.n_owners > 1)
+        hipLaunchKernelGGL(k_count_sorted_owned, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                           sk, sv, n, lo, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), cnt, c.n_owners, c.owner);
+    else
+        hipLaunchKernelGGL(k_count_sorted, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
+                           sk, sv, n, c.seed, c.wstart.as<u32>(), cnt);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -290,11 +317,12 @@ int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stri
 // sum places the probes' lists back to back in probe order (= the reference's enumeration order within a
 // position, src/seed_search.c:522-549), and the lists go to off[position] in the hit array.
 #define LZ_FILL_GROUP 16
+template <bool OWNED>
 __global__ void __launch_bounds__(LZ_TPB)
 k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
             const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
-            u64 base, u64* __restrict__ keys)
+            u64 base, u64* __restrict__ keys, u32 n_owners, u32 owner)
 {
     const u32 lane = threadIdx.x & 63u, p = lane & (LZ_FILL_GROUP - 1), g = lane >> 4;
     const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane
@@ -319,10 +347,11 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
         u64* out = have ? keys + (off[i] - base) : keys;
         u32 carry = 0;
         for (int r = 0; r < sd.nprobes; r += LZ_FILL_GROUP) {   // uniform trip count
-            u32 a = 0, len = 0;
+            u32 a = 0, len = 0, full = 0;
             if (have && r + (int)p < sd.nprobes) {
                 const u32 w = packed ^ sd.probe_xor[r + p];
-                a = wstart[w]; len = wstart[w + 1] - a;
+                a = wstart[w]; full = wstart[w + 1] - a; len = full;
+                if (OWNED) { len = 0; for (u32 jj = 0; jj < full; jj++) len += lz_owned(wpos[a + jj], pos2, n_owners, owner) ? 1u : 0u; }
             }
             u32 incl = len;                                  // inclusive prefix over the 16-lane group
 #pragma unroll
@@ -332,7 +361,8 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             }
             const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
             u64* o = out + carry + (incl - len);
-            for (u32 jj = 0; jj < len; jj++) o[jj] = lz_hit_key(wpos[a + jj], pos2);
+            if (OWNED) { for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) *o++ = lz_hit_key(p1, pos2); } }
+            else for (u32 jj = 0; jj < len; jj++) o[jj] = lz_hit_key(wpos[a + jj], pos2);
             carry += total;
         }
     }
@@ -342,8 +372,12 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
 {
     if (n == 0 || i1 <= i0) return 0;
     c.timer.begin("k_fill_hits", c.stream);
-    hipLaunchKernelGGL(k_fill_hits, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
-                       lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys);
+    if (c.n_owners > 1)
+        hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, c.n_owners, c.owner);
+    else
+        hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, 1u, 0u);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;

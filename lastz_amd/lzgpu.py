@@ -58,7 +58,8 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdo
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_device_copy",
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
-           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window"]
+           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window",
+           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order"]
 
 
 class LzGpuError(RuntimeError):
@@ -208,6 +209,15 @@ class Lib:
             C.memmove(_ptr(res), out, n.value * HSP_DTYPE.itemsize)
         self._f("free")(out)
         return res
+
+    def set_bucket_owner(self, n_owners, owner):
+        self._check(self._f("set_bucket_owner")(C.c_uint32(n_owners), C.c_uint32(owner)), "lzgpu_set_bucket_owner")
+
+    def last_hsp_order(self, n):
+        """(n, 2) uint64 sort words of the HSPs the last search returned (see include/lzgpu.h)"""
+        out = np.zeros((n, 2), dtype=np.uint64)
+        self._check(self._f("last_hsp_order")(_ptr(out), C.c_uint64(n)), "lzgpu_last_hsp_order")
+        return out
 
     def target_upload(self, t):
         t = np.ascontiguousarray(t, dtype=np.uint8)

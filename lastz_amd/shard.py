@@ -37,6 +37,19 @@ def merge_units(per_rank: Sequence[dict]) -> List[Tuple[Tuple[int, int], object]
     return sorted(out.items(), key=lambda kv: kv[0])
 
 
+def merge_bucket_owners(per_owner):
+    """Sharding inside one query by hashed-diagonal ownership (lzgpu_set_bucket_owner): per_owner[r] =
+    (hsps, order) with order = the (n, 2) uint64 sort words of lzgpu_last_hsp_order.  Returns the HSPs in
+    the single-process discovery order (query position, probe index, target position descending)."""
+    import numpy as np
+    hs = np.concatenate([h for h, _ in per_owner]) if per_owner else np.zeros(0)
+    od = np.concatenate([o.reshape(-1, 2) for _, o in per_owner]) if per_owner else np.zeros((0, 2), dtype=np.uint64)
+    if len(hs) == 0:
+        return hs
+    idx = np.lexsort((od[:, 1], od[:, 0]))                  # primary: word 0, then word 1; owners never tie
+    return hs[idx]
+
+
 def broadcast_buffers(dist, tensors, src: int = 0):
     """One broadcast per table buffer (target bytes, wstart, wpos).  On the GPU these are zero-copy
     views of the library's device allocations and the backend is RCCL over xGMI; the CPU tests

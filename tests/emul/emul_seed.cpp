@@ -146,7 +146,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         // candidates arrive in arbitrary (atomic) order on the GPU: shuffle deterministically here
         std::reverse(recs.begin(), recs.end());
         rc = lzh_finish_hsps(recs.data(), (u32)recs.size(), E.traw.data() + LZ_SEQ_PAD, a->query, E.sd, E.ctb,
-                             a->hsp_threshold, a->entropic, fin);
+                             a->hsp_threshold, a->entropic, fin, nullptr, nullptr);
         if (rc) return rc;
         E.cnt.hsps += fin.size();
     }

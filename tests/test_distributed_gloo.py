@@ -76,6 +76,18 @@ def _worker(rank, world, port, root, out_path):
     dist.destroy_process_group()
 
 
+def test_merge_bucket_owners_restores_discovery_order():
+    rng = np.random.default_rng(5)
+    n = 5000
+    order = np.stack([rng.integers(0, 1 << 40, n, dtype=np.uint64) | np.uint64(0), rng.integers(0, 1 << 32, n, dtype=np.uint64)], axis=1)
+    order = order[np.lexsort((order[:, 1], order[:, 0]))]
+    hsps = np.arange(n)                                      # stand-in payload: the rank in discovery order
+    owner = rng.integers(0, 3, n)
+    per_owner = [(hsps[owner == r], order[owner == r]) for r in range(3)]
+    assert (shard.merge_bucket_owners(per_owner) == hsps).all()
+    assert len(shard.merge_bucket_owners([(hsps[:0], order[:0])])) == 0
+
+
 def test_two_ranks_equal_one(tmp_path):
     from oracle import lzo
     from lastz_amd import seqio

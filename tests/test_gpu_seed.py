@@ -136,6 +136,37 @@ def test_matrix_with_more_than_8_classes(gpu):
     _same_hsps(gpu, tab, q, masked)                         # and back: the class tables are re-derived
 
 
+def test_bucket_ownership_sharding_inside_one_query(gpu):
+    """the hashed-diagonal buckets dealt out to n processes; merged lists == the single list"""
+    from lastz_amd import shard
+    t, q = seqio.synth_pair(400000, 300000, seed=41, block_min=500, block_max=6000)
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    try:
+        for qq in (q, seqio.revcomp(q)):
+            gpu.set_bucket_owner(1, 0)
+            gpu.counters_reset()
+            whole = gpu.seed_hit_search(masked, q=qq)
+            cw = gpu.counters()
+            want, _ = lzo.seed_hit_search(tab, qq, masked)
+            assert len(whole) == len(want) and (whole == want).all()
+            for n in (2, 3, 8):
+                parts, tot = [], dict(raw_hits=0, extensions=0, bp_extended=0, hsps=0)
+                for r in range(n):
+                    gpu.set_bucket_owner(n, r)
+                    gpu.counters_reset()
+                    h = gpu.seed_hit_search(masked, q=qq)
+                    parts.append((h, gpu.last_hsp_order(len(h))))
+                    c = gpu.counters()
+                    assert c["words"] == cw["words"]
+                    for k in tot: tot[k] += c[k]
+                merged = shard.merge_bucket_owners(parts)
+                assert len(merged) == len(whole) and (merged == whole).all()
+                assert all(tot[k] == cw[k] for k in tot)
+    finally:
+        gpu.set_bucket_owner(1, 0)
+
+
 def test_diag_hash_collisions_and_long_hsps(gpu):
     """tandem repeats: thousands of hits per hashed diagonal, clipped left extensions"""
     t, q = H.load_case("adversarial")
