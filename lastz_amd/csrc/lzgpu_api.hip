@@ -159,6 +159,7 @@ extern "C" void lzgpu_shutdown(void)
     if (c.ev_init) (void)hipEventDestroy(c.ev_init);
     c.ev_init = nullptr; c.stream2 = nullptr;
     c.stream = nullptr; c.inited = false; c.have_table = false; c.device = -1;
+    c.n_owners = 1; c.owner = 0; c.last_order.clear();
 }
 
 extern "C" void lzgpu_free(void* p) { free(p); }
