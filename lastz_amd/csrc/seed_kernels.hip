@@ -389,21 +389,24 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
 // are still going, and a wave that serves them in place issues every further block for all 64 lanes.  The
 // unfinished scans of the 256 hits of a block are therefore queued in LDS as independent tasks (left ones
 // from the front, right ones from the back) and served densely: one lane per task, to completion.
+#ifndef LZ_PROBE_TPB
+#define LZ_PROBE_TPB 256              // hits (threads) per block of k_probe_hits: the pool the task queue packs
+#endif
 struct LzScanTask { u32 s; s32 run, best, stop, diag; u32 side; };
-__global__ void __launch_bounds__(LZ_TPB)
+__global__ void __launch_bounds__(LZ_PROBE_TPB)
 k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* __restrict__ score_tab_g,
              u32* __restrict__ summ)
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
     __shared__ s32 tab8[64];
-    __shared__ LzScanTask task[2 * LZ_TPB];
+    __shared__ LzScanTask task[2 * LZ_PROBE_TPB];
     __shared__ u32 n_left, n_right;
-    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_TPB) tab[k] = score_tab_g[k];
+    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PROBE_TPB) tab[k] = score_tab_g[k];
     if (threadIdx.x < 64) tab8[threadIdx.x] = score_tab_g[(threadIdx.x >> 3) * LZ_NCLASS + (threadIdx.x & 7)];
     if (threadIdx.x == 0) { n_left = 0; n_right = 0; }
     __syncthreads();
     const bool fast = P.cls8 != 0;
-    const u64 i = (u64)blockIdx.x * LZ_TPB + threadIdx.x;
+    const u64 i = (u64)blockIdx.x * LZ_PROBE_TPB + threadIdx.x;
     LzProbeSt st;
     st.alive_l = st.alive_r = false;
     if (i < n) lz_probe_head(P, tab, tab8, fast, keys[i], st);
@@ -413,13 +416,13 @@ k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* _
         task[slot_l] = { st.sl, st.runl, st.bestl, st.stopl, st.diag, 0u };
     }
     if (st.alive_r) {
-        slot_r = 2 * LZ_TPB - 1 - (int)atomicAdd(&n_right, 1u);
+        slot_r = 2 * LZ_PROBE_TPB - 1 - (int)atomicAdd(&n_right, 1u);
         task[slot_r] = { st.sr, st.runr, st.bestr, st.stopr, st.diag, 1u };
     }
     __syncthreads();
     const u32 nl = n_left, nr = n_right;
-    for (u32 k = threadIdx.x; k < nl + nr; k += LZ_TPB) {
-        LzScanTask& q = task[k < nl ? k : 2 * LZ_TPB - 1 - (k - nl)];
+    for (u32 k = threadIdx.x; k < nl + nr; k += LZ_PROBE_TPB) {
+        LzScanTask& q = task[k < nl ? k : 2 * LZ_PROBE_TPB - 1 - (k - nl)];
         u32 s = q.s; s32 run = q.run, best = q.best;
         bool alive;
         if (q.side) alive = lz_scan_continue<true>(P, tab, tab8, fast, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
@@ -436,7 +439,7 @@ int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, co
 {
     if (n == 0) return 0;
     c.timer.begin("k_probe_hits", c.stream);
-    hipLaunchKernelGGL(k_probe_hits, dim3((unsigned)((n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+    hipLaunchKernelGGL(k_probe_hits, dim3((unsigned)((n + LZ_PROBE_TPB - 1) / LZ_PROBE_TPB)), dim3(LZ_PROBE_TPB), 0, c.stream,
                        P, keys, n, score_tab, summ);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
