@@ -85,6 +85,28 @@ static int msp_left_right(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbour
     return 1;
 }
 
+// the reference's walk (src/gapped_extend.c:3953-4028), kept as the yardstick of lzh_selftest_neighbours
+static int msp_left_right_plain(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbours& nb)
+{
+    u32 right = 0xFFFFFFFFu, left = 0xFFFFFFFFu;
+    nb.la = nb.ls = nb.ra = nb.rs = -1;
+    for (size_t o = 0; o < S.obi.size(); o++) {
+        const LzDpAlign& al = S.aligns[S.obi[o]];
+        if (al.pos1 > pos1) break;
+        if (al.end1 < pos1) continue;
+        s32 bp = -1;
+        for (s32 k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].e1 >= pos1) { bp = k; break; }
+        if (bp < 0) continue;
+        const LzDpSeg& g = S.segs[bp];
+        if (g.type == LZ_HORZ_SEG) return -1;
+        s32 x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+        if (x == 0) return 0;
+        if (x > 0 && (u32)x < right) { right = (u32)x; nb.ra = S.obi[o]; nb.rs = bp; }
+        else if (x < 0 && (u32)(-x) < left) { left = (u32)(-x); nb.la = S.obi[o]; nb.ls = bp; }
+    }
+    return 1;
+}
+
 // align_left_right, src/gapped_extend.c:4078-4180
 static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
 {
@@ -428,3 +450,37 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     }
     return 0;
 }
+
+int lzh_selftest_neighbours(u32 seed, u32 n_aligns, u32 n_queries)
+{
+    u64 x = (u64)seed * 0x9E3779B97F4A7C15ull + 3;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (u32)(x >> 12); };
+    LzHostSnapshot S;
+    const u32 span = 200000;
+    for (u32 a = 0; a < n_aligns; a++) {                        // alignments of diagonal / vertical pieces, overlapping freely
+        LzDpAlign m; memset(&m, 0, sizeof(m));
+        u32 p1 = rnd() % span, p2 = rnd() % span;
+        m.pos1 = p1; m.pos2 = p2; m.first_seg = (s32)S.segs.size();
+        const u32 pieces = 1 + rnd() % 5;
+        for (u32 k = 0; k < pieces; k++) {
+            LzDpSeg g; const u32 len = 1 + rnd() % (rnd() % 8 == 0 ? 5000 : 300);
+            if (k % 2 == 0) { g.type = LZ_DIAG_SEG; g.b1 = p1; g.b2 = p2; g.e1 = p1 + len - 1; g.e2 = p2 + len - 1; p1 += len; p2 += len; }
+            else            { g.type = LZ_VERT_SEG; g.b1 = p1; g.b2 = p2; g.e1 = p1 + len - 1; g.e2 = p2; p1 += len; }
+            S.segs.push_back(g);
+        }
+        m.last_seg = (s32)S.segs.size() - 1; m.end1 = p1 - 1; m.end2 = p2 - 1;
+        S.aligns.push_back(m);
+        insert_align(S, (s32)S.aligns.size() - 1);
+    }
+    int bad = 0;
+    for (u32 k = 0; k < n_queries; k++) {
+        u32 p1, p2;
+        if (k % 3 == 0 && !S.aligns.empty()) { const LzDpSeg& g = S.segs[rnd() % S.segs.size()]; p1 = g.b1 + rnd() % (g.e1 - g.b1 + 1); p2 = g.b2 + (rnd() % 7) - 3; }
+        else { p1 = rnd() % (span + 6000); p2 = rnd() % (span + 6000); }
+        Neighbours a, b;
+        const int ra = msp_left_right(S, p1, p2, a), rb = msp_left_right_plain(S, p1, p2, b);
+        if (ra != rb || (ra == 1 && (a.la != b.la || a.ls != b.ls || a.ra != b.ra || a.rs != b.rs))) bad++;
+    }
+    return bad;
+}
+

@@ -43,3 +43,8 @@ void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* 
 
 int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,
                       std::vector<lz_align>& out, std::vector<u32>& out_ops, LzGappedStats& st);
+
+// Test hook: the indexed neighbour search (msp_left_right with obi_maxend) against the reference's plain
+// walk over every alignment starting at or before the anchor, on random snapshots.  Returns mismatches.
+int lzh_selftest_neighbours(u32 seed, u32 n_aligns, u32 n_queries);
+

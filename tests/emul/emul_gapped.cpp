@@ -107,3 +107,6 @@ extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, 
     *n_out = al.size(); *n_ops = op.size();
     return 0;
 }
+
+extern "C" int emul_selftest_neighbours(u32 seed, u32 n_aligns, u32 n_queries) { return lzh_selftest_neighbours(seed, n_aligns, n_queries); }
+

@@ -85,6 +85,13 @@ def test_obstacle_course(L):
     assert st["rounds"] > 3
 
 
+def test_indexed_neighbour_search_equals_plain_walk(L):
+    """msp_left_right with the running-max index vs the reference's walk, random snapshots (incl. > 64 overlaps)"""
+    L.emul_selftest_neighbours.restype = C.c_int
+    for seed, na in ((1, 0), (2, 1), (3, 40), (4, 600), (5, 3000), (6, 25000)):
+        assert L.emul_selftest_neighbours(C.c_uint32(seed), C.c_uint32(na), C.c_uint32(20000)) == 0
+
+
 def test_traceback_truncation_rule(L):
     """the reference truncates an alignment when its traceback arena runs out (:3640-3661)"""
     t, q = H.load_case("synth_overlap")
