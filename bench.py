@@ -309,9 +309,9 @@ def main():
         # algorithmic bytes per step (both strands), SURVEY.md 8(d): B_seed = W*(1+4V) + 8H + 4E + X
         V = sd.num_probes
         # split over the kernels that do each part: the table probes and chain links (count, fill), the
-        # bases the X-drop scans touch (phase A = k_probe_hits, which scans every hit), the diagEnd
-        # read / write per hit / extension (phase B = k_extend, which settles hits from the summaries)
-        alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_probe_hits": X, "k_extend": 4 * Hh + 4 * E}
+        # bases the X-drop scans touch (phase A = k_probe_part, which scans every hit and partitions the records),
+        # the diagEnd read / write per hit / extension (phase B = k_settle, which settles hits from the summaries)
+        alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_probe_part": X, "k_settle": 4 * Hh + 4 * E}
         b_seed = W * (1 + 4 * V) + 8 * Hh + 4 * E + X
         kern_ms = {k: v["ms"] / K for k, v in prof.items()}
         dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k], default=None)

@@ -30,7 +30,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload")]
+            flags = FLAGS if src.endswith(".hip") else ["-x", "c++"] + [f for f in FLAGS if not f.startswith("--offload")]   # host-only sources: no device pass
             cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

@@ -149,6 +149,11 @@ struct DpBufs {
     DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act;
 };
 static DpBufs g_dp;
+void lz_dp_release_statics()
+{
+    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act };
+    for (DevBuf* x : b) x->release();
+}
 
 struct HipDpExec : LzDpExecutor {
     LzCtx& c;

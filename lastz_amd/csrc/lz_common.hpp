@@ -417,87 +417,24 @@ LZ_HD u32 lz_probe_hit(const LzExtendParams& P, const s32* score_tab, const s32*
     return lz_probe_summary(P, st);
 }
 
-// ---- phase B.  One bucket (= one value of hashedDiag) of the diagonal hash: process its hits of this chunk
-// in enumeration order.  This is process_for_simple_hit + xdrop_extend_seed_hit
-// (src/seed_search.c:1056-1192, 2528-2959) with diagEnd[h] held in a register.
-//   keys[i0..i1)  this bucket's hits, already in discovery order
-//   dend          diagEnd[h] on entry (0 == inactive, src/seed_search.c:1097-1111)
-// Returns the updated diagEnd[h].  emit(rec) is called for every extension scoring >= min_score.
-//
-// Shape: ONE flat loop per lane.  Each trip either starts the lane's next hit or advances the
-// current hit by one 16-base block on the left AND on the right (the two X-drop scans of the
-// reference are independent of each other: loop 2 restarts from the seed end with runScore=0,
-// :2663-2682), so the lanes of a wave never wait for each other per hit, the two serial
-// score chains give each lane 2-way ILP, and every memory access is a 16-byte load whose 16
-// score look-ups are issued together.  The per-base semantics are exactly the reference's:
-// the X-drop test "run >= best - xDrop" gates each further base (:2623, :2684).
+// ---- phase B, the slow path.  One raw hit whose phase-A summary does not settle it (an HSP candidate, or a
+// scan that ran into the phase-A cap): loops 1 and 2 of xdrop_extend_seed_hit with the bucket's real diagEnd
+// (src/seed_search.c:2612-2616, 2623-2632, 2684-2693), 16 bases per trip on each side (the two scans are
+// independent of each other: loop 2 restarts from the seed end with runScore = 0, :2663-2682).  Returns the
+// bucket's new diagEnd (:2785-2789); emit(rec) is called when leftScore + rightScore >= min_score.
 template <class Emit>
-LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*32]*/,
-                           const u64* keys, const u32* summ, u32 i0, u32 i1, u32 dend,
-                           u64& n_ext, u64& n_bp, Emit&& emit)
+LZ_HD u32 lz_reextend(const LzExtendParams& P, const s32* score_tab /*[32*32]*/, u32 pos2, s32 diag, u32 dend,
+                      u64& n_bp, Emit&& emit)
 {
-    const u32 L = P.seed_len;
     const s32 xd = P.xdrop;
-    u32 i = i0;
-    bool in_hit = false;
-    u32 pos1 = 0, pos2 = 0, sl = 0, sr = 0, left_start = 0, right_stop = 0;
-    s32 diag = 0, stopl = 0, stopr = 0, runl = 0, bestl = 0, runr = 0, bestr = 0;
-    bool alive_l = false, alive_r = false;
-
-    for (;;) {
-        if (!in_hit) {
-            // Settle hits straight from their phase-A summaries for as long as that is possible
-            // (all but the hits phase A flagged SLOW: possible HSPs and scans that ran into the cap);
-            // the loads of a group of LZ_FAST_GROUP (key, summary) pairs are issued together.
-            bool start = false;
-            for (int budget = LZ_FAST_RUN; budget > 0 && i < i1 && !start; budget--) {
-                u64 kk[LZ_FAST_GROUP]; u32 ss[LZ_FAST_GROUP];
-                const u32 ng = (i1 - i < (u32)LZ_FAST_GROUP) ? (i1 - i) : (u32)LZ_FAST_GROUP;
-                if (ng == (u32)LZ_FAST_GROUP) { __builtin_memcpy(kk, keys + i, 8 * LZ_FAST_GROUP); __builtin_memcpy(ss, summ + i, 4 * LZ_FAST_GROUP); }
-                else {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-                    for (int u = 0; u < LZ_FAST_GROUP; u++) { kk[u] = ((u32)u < ng) ? keys[i + u] : 0; ss[u] = ((u32)u < ng) ? summ[i + u] : 0; }
-                }
-                u32 taken = ng;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-                for (int u = 0; u < LZ_FAST_GROUP; u++) {
-                    if (start || (u32)u >= ng) continue;
-                    const u32 p2 = (u32)kk[u];
-                    if (dend > p2 - L) continue;                    // :1113
-                    n_ext++;
-                    const u32 sm = ss[u];
-                    if (!(sm & LZ_SUMM_SLOW)) {
-                        // The unclipped scans scored below the threshold.  A left scan clipped at
-                        // diagEnd walks a prefix of the same bases (its best can only be lower: still
-                        // no HSP) and the right scan does not depend on it: only the count of bases
-                        // differs, min(unclipped, room).
-                        const u32 room = p2 - dend, dlo = LZ_SUMM_DLO(sm);
-                        const u32 extent = p2 + LZ_SUMM_DEXT(sm);   // :2785
-                        n_bp += (dlo < room ? dlo : room) + LZ_SUMM_DEXT(sm);   // :2818
-                        if (extent > dend) dend = extent;
-                        continue;
-                    }
-                    pos2 = p2;
-                    diag = (s32)(u32)(kk[u] >> 32);
-                    start = true;
-                    taken = (u32)u + 1u;
-                }
-                i += taken;
-            }
-            if (!start) { if (i >= i1) break; continue; }
-            pos1 = pos2 + (u32)diag;
-            stopl = (s32)dend + diag;  if (stopl < 0) stopl = 0;                               // :2612-2616
-            stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
-            sl = sr = left_start = right_stop = pos1;
-            runl = bestl = runr = bestr = 0;
-            alive_l = ((s32)sl > stopl) && (0 >= -xd);
-            alive_r = ((s32)sr < stopr) && (0 >= -xd);
-            in_hit = true;
-        }
+    const u32 pos1 = pos2 + (u32)diag;
+    s32 stopl = (s32)dend + diag;  if (stopl < 0) stopl = 0;                                 // :2612-2616
+    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag; // :2675-2677
+    u32 sl = pos1, sr = pos1, left_start = pos1, right_stop = pos1;
+    s32 runl = 0, bestl = 0, runr = 0, bestr = 0;
+    bool alive_l = ((s32)sl > stopl) && (0 >= -xd);
+    bool alive_r = ((s32)sr < stopr) && (0 >= -xd);
+    while (alive_l || alive_r) {
         if (alive_l) {                                          // loop 1, :2623-2632, 16 bases
             const u32 room = (u32)((s32)sl - stopl);
             const LzVec16 tv = lz_load16(P.tcode + sl - 16);
@@ -546,19 +483,16 @@ LZ_HD u32 lz_extend_bucket(const LzExtendParams& P, const s32* score_tab /*[32*3
             }
             alive_r = go && ((s32)sr < stopr);
         }
-        if (!alive_l && !alive_r) {                             // both scans have stopped
-            const u32 extent = (u32)((s32)sr - diag);           // :2785 (where loop 2 STOPPED)
-            if (extent > dend) dend = extent;
-            n_bp += (u64)(sr - sl);                             // :2818
-            const s32 sim = bestl + bestr;
-            if (sim >= P.min_score) {
-                LzHspRec r;
-                r.seed_pos1 = pos1; r.seed_pos2 = pos2;
-                r.end1 = right_stop; r.length = right_stop - left_start; r.score = sim;
-                emit(r);
-            }
-            in_hit = false;
-        }
+    }
+    const u32 extent = (u32)((s32)sr - diag);                   // :2785 (where loop 2 STOPPED)
+    if (extent > dend) dend = extent;
+    n_bp += (u64)(sr - sl);                                     // :2818
+    const s32 sim = bestl + bestr;
+    if (sim >= P.min_score) {
+        LzHspRec r;
+        r.seed_pos1 = pos1; r.seed_pos2 = pos2;
+        r.end1 = right_stop; r.length = right_stop - left_start; r.score = sim;
+        emit(r);
     }
     return dend;
 }

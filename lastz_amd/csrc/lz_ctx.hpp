@@ -36,8 +36,12 @@ struct SeqSlot {                    // a sequence resident in HBM
     DevBuf raw;                     // LZ_SEQ_PAD + len + LZ_SEQ_PAD bytes
     DevBuf code;                    // same geometry, code bytes (see lz_common.hpp)
     DevBuf dp;                      // same geometry, DP score-class codes (unmasked scoring), B3 only
-    DevBuf nib;                     // 4-bit class codes, two bases per byte (phase A; built when all classes are < 8)
+    DevBuf nib;                     // 4-bit class codes, two bases per byte (byte-code scans; built when all classes are < 8)
     bool   have_nib = false;
+    DevBuf two, spc;                // 2-bit codes and the 1-bit "not A,C,G,T" mask (lz_lut.hpp), rebuilt with the codes
+    DevBuf occ_dev;                 // [256] u32: which byte values occur
+    u8     occ[256] = { 0 };        // ... on the host
+    bool   has_special = false;     // some byte of the sequence is outside the 2-bit alphabet
     u32    len = 0;
     bool   have_raw = false;
     uint64_t code_key = 0;          // hash of the (class map, charToBits) the codes were built with
@@ -69,9 +73,11 @@ struct LzCtx {
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
     DevBuf wiv, wsk, wsv;           // position index; (word, position) sorted by word
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
-    DevBuf keys_a, keys_b;          // hit keys, double buffer for the radix sort
-    DevBuf summ_a, summ_b;          // phase-A summaries, travelling with the keys
-    DevBuf keys_b2, summ_b2;        // second output set (double buffering across chunks)
+    DevBuf keys_a;                  // hit keys of the current chunk, discovery order
+    DevBuf recs[2], bin_base[2];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
+                                    // phase B of a chunk runs while the next chunk is filled / scanned / partitioned
+    DevBuf hist, hist_part;         // per-tile partition histogram and its block sums
+    DevBuf lut, m16;                // phase-A tables (lz_lut.hpp)
     DevBuf sort_tmp, scan_tmp;
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
     DevBuf score_tab;               // [32*32] s32
@@ -81,6 +87,8 @@ struct LzCtx {
     DevBuf tb_keys, tb_vals, tb_keys2, tb_vals2;   // table build scratch
     u32 n_owners = 1, owner = 0;      // bucket ownership (lzgpu_set_bucket_owner)
     std::vector<u64> last_order;      // two sort words per HSP of the last search
+    int min_scan_mode = 0;            // lzgpu_set_scan_mode
+    int last_scan_mode = -1;          // phase-A scan mode of the last search (0/1: look-up tables without/with special masks, 2: byte codes)
     u64 hit_capacity = (1ull << 28);
     u64 hsp_capacity = (1ull << 24);
 
@@ -104,7 +112,10 @@ int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stri
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
-int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ);
-int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n);
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, u32 n, u32* diag_end,
+struct LzLutParams; struct LzLutEntry;
+int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
+int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base);
+int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
+                   const s32* score_tab, const LzLutEntry* lut, const s32* m16, const u32* hist, const u32* part, u64* recs);
+int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

@@ -5,6 +5,7 @@
 #include <thread>
 #include <vector>
 #include "lz_host.hpp"
+#include "lz_lut.hpp"
 
 // strict-seed compilation, restating src/seeds.c:321-640 (parse_one_seed; flips in
 // "maintainFlippedBitOrder" order, :603-613) and :1399-1417 (best_shift)
@@ -114,6 +115,63 @@ u32 lzh_small_classes(const u8 rowc[256], const u8 colc[256])
 {
     for (int b = 0; b < 256; b++) if (rowc[b] >= 8 || colc[b] >= 8) return 0;
     return 1;
+}
+
+// ---- phase-A look-up tables
+int lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], const u8 qocc[256], s32 xdrop, s32 M4[16])
+{
+    if (xdrop < 0 || xdrop > 15000) return 0;
+    // plain bytes: the score depends on the 2-bit codes only (among the bytes that occur)
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+        bool have = false; s32 v = 0;
+        for (int r = 1; r < 256; r++) {
+            if (ctb[r] != a) continue;
+            for (int c = 1; c < 256; c++) {
+                if (ctb[c] != b) continue;
+                const bool occ = tocc[r] && qocc[c];
+                const s32 x = sub[256 * r + c];
+                if (occ) { if (have && x != v) return 0; if (!have) { have = true; v = x; } }
+            }
+        }
+        if (!have) {                                            // the pair never occurs: any representative will do
+            for (int r = 1; r < 256 && !have; r++) if (ctb[r] == a) for (int c = 1; c < 256 && !have; c++) if (ctb[c] == b) { v = sub[256 * r + c]; have = true; }
+        }
+        if (v > 5000 || v < -5000) return 0;
+        M4[4 * a + b] = v;
+    }
+    // special bytes end a scan: whatever they meet scores below -xDrop
+    for (int r = 0; r < 256; r++) {
+        if (!tocc[r]) continue;
+        for (int c = 0; c < 256; c++) {
+            if (!qocc[c]) continue;
+            if ((ctb[r] < 0 || ctb[c] < 0) && (s64)sub[256 * r + c] >= -(s64)xdrop) return 0;
+        }
+    }
+    // no three-base group loses more than xDrop from a maximum set inside the group
+    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
+        const s32 d1 = -M4[i], d2 = -(M4[i] + M4[j]);           // drop over the next base / the next two bases
+        if (d1 > xdrop || d2 > xdrop) return 0;
+    }
+    return 1;
+}
+
+void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab)
+{
+    for (int dir = 0; dir < 2; dir++)                           // 0: right scans (low bases first), 1: left scans (high bases first)
+        for (u32 idx = 0; idx < LZ_LUT_ENTRIES; idx++) {
+            const u32 tf = idx >> 6, qf = idx & 63u;
+            s32 p = 0, minp = 0x7FFFFFFF, maxp = -0x7FFFFFFF;
+            for (u32 b = 0; b < 3; b++) {
+                const u32 sh = dir == 0 ? 2u * b : 2u * (2u - b);
+                p += M4[(((tf >> sh) & 3u) << 2) | ((qf >> sh) & 3u)];
+                if (p < minp) minp = p;
+                if (p > maxp) maxp = p;
+            }
+            const u32 A = minp < 0 ? (u32)(-minp) : 0u;
+            const s32 B = xdrop - (maxp > 0 ? maxp : 0);        // the margin never exceeds xDrop; -15000 <= B <= 15000 (lzh_lut_eligible)
+            tab[dir * LZ_LUT_ENTRIES + idx].ab = A | ((u32)(B & 0xFFFF) << 16);
+            tab[dir * LZ_LUT_ENTRIES + idx].c = p;
+        }
 }
 
 // src/dna_utilities.c:2888-2936 (compute_entropy with lowerOk == false); same operation order

@@ -12,6 +12,13 @@ int  lzh_score_classes(const s32* sub, u8 rowc[256], u8 colc[256], s32 tab[LZ_NC
 u32  lzh_small_classes(const u8 rowc[256], const u8 colc[256]);    // 1 when every class id is < 8
 double lzh_hsp_entropy(const u8* s, const u8* t, int len);
 
+// ---- phase-A look-up tables (lz_lut.hpp).  tocc / qocc say which byte values occur in the target / query.
+// lzh_lut_eligible: 1 when the scans of this (matrix, xDrop, sequences) can run three bases per step on 2-bit
+// codes -- M4 receives the 4 x 4 matrix over charToBits codes -- else 0 (the byte-code scans run instead).
+struct LzLutEntry;
+int  lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], const u8 qocc[256], s32 xdrop, s32 M4[16]);
+void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab /*[2 * 4096]: right scans, then left scans*/);
+
 struct LzChunk { u32 i0, i1; u64 base, nh; };
 // Split query positions [0,n) into chunks of at most cap raw hits.  off_at(i) must return the
 // exclusive prefix sum of the per-position hit counts at i (i in [0,n]); samples are taken every

@@ -12,10 +12,12 @@
 #include <algorithm>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
+#include "lz_lut.hpp"
 
 // ------------------------------------------------------------------------------ context
 
 static LzCtx g_ctx;
+static void lz_release_statics();
 LzCtx& lz_ctx() { return g_ctx; }
 
 int lz_fail(int code, const char* fmt, ...)
@@ -132,6 +134,7 @@ extern "C" int lzgpu_init(int device_index)
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_extended[k], hipEventDisableTiming));
     }
     LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_init, hipEventDisableTiming));
+    if (const char* sm = getenv("LZGPU_SCAN_MODE")) { const int v = atoi(sm); if (v >= 0 && v <= 2) g_ctx.min_scan_mode = v; }
     if (const char* hc = getenv("LZGPU_HIT_CAPACITY")) { const long long v = atoll(hc); if (v >= 1024 && v <= (1ll << 31)) g_ctx.hit_capacity = (u64)v; }
     g_ctx.device = device_index;
     g_ctx.inited = true;
@@ -146,12 +149,13 @@ extern "C" void lzgpu_shutdown(void)
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
     if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.keys_b, &c.summ_a, &c.summ_b, &c.keys_b2, &c.summ_b2,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.recs[0], &c.recs[1], &c.bin_base[0], &c.bin_base[1], &c.hist, &c.hist_part, &c.lut, &c.m16,
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); }
-    c.target.dp.release(); c.target.nib.release();
+    for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); kv.second.two.release(); kv.second.spc.release(); kv.second.occ_dev.release(); }
+    c.target.dp.release(); c.target.nib.release(); c.target.two.release(); c.target.spc.release(); c.target.occ_dev.release();
+    lz_release_statics();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
     if (c.stream2) (void)hipStreamDestroy(c.stream2);
@@ -210,10 +214,25 @@ static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
         if ((rc = lzk_pack_nibbles(c, s.code.as<u8>(), s.nib.as<u8>(), total / 2))) return rc;
         s.have_nib = true;
     }
+    // 2-bit codes, special mask and the set of byte values that occur (phase A on look-up tables, lz_lut.hpp)
+    const u32 nmask = (u32)(((size_t)s.len + 2 * LZ_PAD2 + 7) / 8 + 16);
+    if ((rc = s.two.ensure((size_t)nmask * 2 + 32))) return rc;
+    if ((rc = s.spc.ensure((size_t)nmask + 32))) return rc;
+    if ((rc = s.occ_dev.ensure(256 * 4))) return rc;
+    LZ_HIP(hipMemsetAsync(s.two.p, 0, (size_t)nmask * 2 + 32, c.stream));
+    LZ_HIP(hipMemsetAsync(s.spc.p, 0xFF, (size_t)nmask + 32, c.stream));
+    if ((rc = lzk_pack2(c, s.code_base(), s.raw_base(), s.len, s.two.as<u8>(), s.spc.as<u8>(), nmask, s.occ_dev.as<u32>()))) return rc;
+    u32 flags[256];
+    LZ_HIP(hipMemcpyAsync(flags, s.occ_dev.p, sizeof(flags), hipMemcpyDeviceToHost, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    s.has_special = false;
+    for (int b = 0; b < 256; b++) { s.occ[b] = flags[b] ? 1 : 0; if (flags[b] && (cls[b] & LZ_CODE_INVALID)) s.has_special = true; }
     return 0;
 }
 
 static DevBuf g_cls_t, g_cls_q, g_cls_tmp;
+void lz_dp_release_statics();                                  // dp_kernels.hip
+static void lz_release_statics() { g_cls_t.release(); g_cls_q.release(); g_cls_tmp.release(); lz_dp_release_statics(); }
 
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len) { return slot_upload(c, s, bytes, len, false); }
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256])
@@ -487,14 +506,17 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     g_hp.lap(2, "chunk plan");
     u64 max_chunk = 0;
     for (auto& ch : chunks) if (ch.nh > max_chunk) max_chunk = ch.nh;
+    const int nsets = chunks.size() > 1 ? 2 : 1;
     if (max_chunk) {
         if ((rc = c.keys_a.ensure((size_t)max_chunk * 8))) return rc;
-        if (a->extend && (rc = c.keys_b.ensure((size_t)max_chunk * 8))) return rc;
-        if (a->extend && (rc = c.summ_a.ensure((size_t)max_chunk * 4))) return rc;
-        if (a->extend && (rc = c.summ_b.ensure((size_t)max_chunk * 4))) return rc;
-        if (a->extend && chunks.size() > 1) {
-            if ((rc = c.keys_b2.ensure((size_t)max_chunk * 8))) return rc;
-            if ((rc = c.summ_b2.ensure((size_t)max_chunk * 4))) return rc;
+        if (a->extend) {
+            const size_t ntiles = (size_t)((max_chunk + 4095) / 4096), nblocks = (ntiles + 255) / 256;
+            for (int k = 0; k < nsets; k++) {
+                if ((rc = c.recs[k].ensure((size_t)max_chunk * 8))) return rc;
+                if ((rc = c.bin_base[k].ensure(257 * 4))) return rc;
+            }
+            if ((rc = c.hist.ensure(ntiles * 256 * 4))) return rc;
+            if ((rc = c.hist_part.ensure(nblocks * 256 * 4))) return rc;
         }
     }
     const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
@@ -508,8 +530,34 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     const bool nibs = P.cls8 && c.target.have_nib && qs->have_nib;
     P.tnib = nibs ? c.target.nib.as<u8>() : nullptr; P.qnib = nibs ? qs->nib.as<u8>() : nullptr;
 
+    // phase A: three bases per step on 2-bit codes when the matrix, xDrop and the bytes that occur allow it
+    // (mode 0 / 1 = without / with special-byte masks), else the byte-code scans (mode 2)
+    LzLutParams Q;
+    Q.t2 = c.target.two.as<u8>(); Q.q2 = qs->two.as<u8>(); Q.tsp = c.target.spc.as<u8>(); Q.qsp = qs->spc.as<u8>(); Q.xdrop = a->xdrop;
+    int mode = 2;
+    if (a->extend) {
+        s32 M4[16];
+        if (lzh_lut_eligible(a->sub, c.geom.char_to_bits, c.target.occ, qs->occ, a->xdrop, M4))
+            mode = (c.target.has_special || qs->has_special) ? 1 : 0;
+        if (mode < c.min_scan_mode) mode = c.min_scan_mode;         // lzgpu_set_scan_mode (tests): 1 = masks even without specials, 2 = byte-code scans
+        if (mode < 2) {
+            static std::vector<LzLutEntry> lut_host; static s32 lut_m4[16]; static s32 lut_x = -1;
+            if (lut_x != a->xdrop || memcmp(lut_m4, M4, sizeof(M4)) != 0 || !c.lut.p || lut_host.empty()) {
+                lut_host.resize(2 * LZ_LUT_ENTRIES);
+                lzh_lut_build(M4, a->xdrop, lut_host.data());
+                if ((rc = c.lut.ensure(lut_host.size() * sizeof(LzLutEntry)))) return rc;
+                if ((rc = c.m16.ensure(sizeof(M4)))) return rc;
+                memcpy(lut_m4, M4, sizeof(M4)); lut_x = a->xdrop;
+                LZ_HIP(hipMemcpyAsync(c.lut.p, lut_host.data(), lut_host.size() * sizeof(LzLutEntry), hipMemcpyHostToDevice, c.stream));
+                LZ_HIP(hipMemcpyAsync(c.m16.p, lut_m4, sizeof(M4), hipMemcpyHostToDevice, c.stream));
+                LZ_HIP(hipStreamSynchronize(c.stream));
+            }
+        }
+    }
+    c.last_scan_mode = mode;
+
     std::vector<lz_hsp> plain;
-    // ---- 3. per chunk: fill -> (phase A probe -> stable bucket sort -> bounds -> phase B bucket-serial pass)
+    // ---- 3. per chunk: fill -> partition offsets -> (phase A scans + stable partition) -> phase B per partition
     LZ_HIP(hipEventRecord(c.ev_init, c.stream));              // state resets above are on stream 1
     LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_init, 0));
     size_t ci = 0;
@@ -526,18 +574,17 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
             for (u64 k : hk) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); }
             continue;
         }
-        // Phase B of this chunk runs on stream2 while stream 1 already fills / probes / sorts the next
-        // chunk (two output sets).  Phase B launches are ordered among themselves on stream2 (diagEnd
+        // Phase B of this chunk runs on stream2 while stream 1 already fills / scans / partitions the next
+        // chunk (two record sets).  Phase B launches are ordered among themselves on stream2 (diagEnd
         // carries from chunk to chunk); a set is rewritten only after the phase B that read it is done.
-        const int set = (int)(ci & 1);
-        u64* kb = set ? c.keys_b2.as<u64>() : c.keys_b.as<u64>();
-        u32* sb = set ? c.summ_b2.as<u32>() : c.summ_b.as<u32>();
-        if ((rc = lzk_probe_hits(c, P, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.summ_a.as<u32>()))) return rc;
+        const int set = (int)(ci & 1) % nsets;
         if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
-        if ((rc = lzk_sort_hits(c, c.keys_a.as<u64>(), kb, c.summ_a.as<u32>(), sb, ch.nh))) return rc;
+        if ((rc = lzk_hist(c, c.keys_a.as<u64>(), ch.nh, c.hist.as<u32>(), c.hist_part.as<u32>(), c.bin_base[set].as<u32>()))) return rc;
+        if ((rc = lzk_probe_part(c, mode, P, Q, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(), c.m16.as<s32>(),
+                                 c.hist.as<u32>(), c.hist_part.as<u32>(), c.recs[set].as<u64>()))) return rc;
         LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
         LZ_HIP(hipStreamWaitEvent(sB, c.ev_sorted[set], 0));
-        if ((rc = lzk_extend(c, P, kb, sb, (u32)ch.nh, c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+        if ((rc = lzk_settle(c, P, c.recs[set].as<u64>(), c.bin_base[set].as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
                              c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, sB))) return rc;
         LZ_HIP(hipEventRecord(c.ev_extended[set], sB));
         ci++;
@@ -623,4 +670,6 @@ extern "C" int lzgpu_last_hsp_order(uint64_t* out, uint64_t n)
     memcpy(out, g_ctx.last_order.data(), g_ctx.last_order.size() * 8);
     return 0;
 }
+extern "C" int lzgpu_last_scan_mode(void) { return g_ctx.last_scan_mode; }
+extern "C" int lzgpu_set_scan_mode(int min_mode) { if (min_mode < 0 || min_mode > 2) return LZGPU_ERR_ARG; g_ctx.min_scan_mode = min_mode; return 0; }
 extern "C" int lzgpu_set_hsp_capacity(uint64_t n) { if (n < 16) return LZGPU_ERR_ARG; g_ctx.hsp_capacity = n; return 0; }

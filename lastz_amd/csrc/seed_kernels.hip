@@ -5,15 +5,17 @@
 // diagEnd[hashedDiag] (src/seed_search.c:1081-1126, 2612-2616, 2785-2789), so the exact
 // parallel form is 65,536 independent, order-preserving streams.  Hits are enumerated in the
 // reference's order (count -> scan -> fill gives every hit its discovery index; the table itself
-// is probed in seed-word order), scanned independently of the hash (phase A, k_probe_hits), stably
-// partitioned by the 16 hash bits (LSD radix sort restricted to key bits 32..47), and each bucket
-// is then walked by one lane with diagEnd[h] in a register (phase B, k_extend).
+// is probed in seed-word order), scanned independently of the hash and stably partitioned by the high
+// 8 hash bits in the same pass (phase A, k_probe_part: three bases per step through an LDS look-up
+// table on 2-bit codes, lz_lut.hpp), and each partition is then dealt out to its 256 buckets inside LDS,
+// every bucket walked by one lane with diagEnd[h] in a register (phase B, k_settle).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include "lz_ctx.hpp"
+#include "lz_lut.hpp"
 
 #define LZ_TPB 256
 
@@ -383,128 +385,391 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
     return 0;
 }
 
-// B2 step 3 (phase A): one thread per raw hit, any order -- capped X-drop scans, 4-byte summary.
-// The kernel is VALU-bound (PMC: 92 % VALU, 79 % texture-address busy), and the scan lengths inside a wave
-// differ: after the blocks every hit gets in lz_probe_head, ~20 % of the left and ~10 % of the right scans
-// are still going, and a wave that serves them in place issues every further block for all 64 lanes.  The
-// unfinished scans of the 256 hits of a block are therefore queued in LDS as independent tasks (left ones
-// from the front, right ones from the back) and served densely: one lane per task, to completion.
-#ifndef LZ_PROBE_TPB
-#define LZ_PROBE_TPB 256              // hits (threads) per block of k_probe_hits: the pool the task queue packs
-#endif
-struct LzScanTask { u32 s; s32 run, best, stop, diag; u32 side; };
-__global__ void __launch_bounds__(LZ_PROBE_TPB)
-k_probe_hits(LzExtendParams P, const u64* __restrict__ keys, u64 n, const s32* __restrict__ score_tab_g,
-             u32* __restrict__ summ)
+// ------------------------------------------------------------------------------------------
+// 2-bit codes + special masks for phase A (lz_lut.hpp), from the code bytes: one thread per mask byte (8 bases).
+// Base i of the sequence is bit (i + LZ_PAD2); bases outside [-LZ_SEQ_PAD, len + LZ_SEQ_PAD) are padding: special.
+__global__ void __launch_bounds__(LZ_TPB)
+k_pack2(const u8* __restrict__ code /*base 0*/, u32 len, u8* __restrict__ two, u8* __restrict__ spc, u32 nmask)
 {
-    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
-    __shared__ s32 tab8[64];
-    __shared__ LzScanTask task[2 * LZ_PROBE_TPB];
-    __shared__ u32 n_left, n_right;
-    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PROBE_TPB) tab[k] = score_tab_g[k];
-    if (threadIdx.x < 64) tab8[threadIdx.x] = score_tab_g[(threadIdx.x >> 3) * LZ_NCLASS + (threadIdx.x & 7)];
-    if (threadIdx.x == 0) { n_left = 0; n_right = 0; }
-    __syncthreads();
-    const bool fast = P.cls8 != 0;
-    const u64 i = (u64)blockIdx.x * LZ_PROBE_TPB + threadIdx.x;
-    LzProbeSt st;
-    st.alive_l = st.alive_r = false;
-    if (i < n) lz_probe_head(P, tab, tab8, fast, keys[i], st);
-    int slot_l = -1, slot_r = -1;
-    if (st.alive_l) {
-        slot_l = (int)atomicAdd(&n_left, 1u);
-        task[slot_l] = { st.sl, st.runl, st.bestl, st.stopl, st.diag, 0u };
+    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
+    if (j >= nmask) return;
+    u32 bits = 0, m = 0;
+    const s64 b0 = (s64)j * 8 - LZ_PAD2;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s64 i = b0 + k;
+        const u32 c = (i >= -(s64)LZ_SEQ_PAD && i < (s64)len + LZ_SEQ_PAD) ? code[i] : (u32)LZ_CODE_INVALID;
+        if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_CODE_BITS(c) << (2 * k);
     }
-    if (st.alive_r) {
-        slot_r = 2 * LZ_PROBE_TPB - 1 - (int)atomicAdd(&n_right, 1u);
-        task[slot_r] = { st.sr, st.runr, st.bestr, st.stopr, st.diag, 1u };
+    spc[j] = (u8)m;
+    two[2 * (size_t)j] = (u8)bits; two[2 * (size_t)j + 1] = (u8)(bits >> 8);
+}
+// which byte values occur in raw[0..len): flags[b] != 0
+__global__ void __launch_bounds__(LZ_TPB)
+k_byte_presence(const u8* __restrict__ raw, u32 len, u32* __restrict__ flags)
+{
+    __shared__ u32 f[256];
+    f[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 nvec = (len + 15u) >> 4;                 // padded buffers: whole 16-byte groups are readable (padding is 0)
+    for (u32 v = blockIdx.x * LZ_TPB + threadIdx.x; v < nvec; v += gridDim.x * LZ_TPB) {
+        const uint4 x = reinterpret_cast<const uint4*>(raw)[v];
+        const u32 w[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 a = w[k];
+            if ((size_t)v * 16 + 4 * k + 0 < len) f[a & 255u] = 1;
+            if ((size_t)v * 16 + 4 * k + 1 < len) f[(a >> 8) & 255u] = 1;
+            if ((size_t)v * 16 + 4 * k + 2 < len) f[(a >> 16) & 255u] = 1;
+            if ((size_t)v * 16 + 4 * k + 3 < len) f[a >> 24] = 1;
+        }
     }
     __syncthreads();
-    const u32 nl = n_left, nr = n_right;
-    for (u32 k = threadIdx.x; k < nl + nr; k += LZ_PROBE_TPB) {
-        LzScanTask& q = task[k < nl ? k : 2 * LZ_PROBE_TPB - 1 - (k - nl)];
-        u32 s = q.s; s32 run = q.run, best = q.best;
-        bool alive;
-        if (q.side) alive = lz_scan_continue<true>(P, tab, tab8, fast, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_R);
-        else        alive = lz_scan_continue<false>(P, tab, tab8, fast, q.diag, q.stop, s, run, best, LZ_PROBE_CAP / 16 - LZ_PROBE_AHEAD_L);
-        q.s = s; q.best = best; q.run = alive ? 1 : 0;          // the result goes back through the task's slot
+    if (f[threadIdx.x]) flags[threadIdx.x] = 1;
+}
+int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256)
+{
+    LZ_HIP(hipMemsetAsync(flags256, 0, 256 * 4, c.stream));
+    c.timer.begin("k_pack2", c.stream);
+    hipLaunchKernelGGL(k_pack2, dim3((nmask + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream, code_base, len, two, spc, nmask);
+    c.timer.end(c.stream);
+    if (len) {
+        u32 blocks = (((len + 15u) >> 4) + LZ_TPB - 1) / LZ_TPB; if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_byte_presence, dim3(blocks), dim3(LZ_TPB), 0, c.stream, raw_base, len, flags256);
     }
-    __syncthreads();
-    if (slot_l >= 0) { st.sl = task[slot_l].s; st.bestl = task[slot_l].best; st.alive_l = task[slot_l].run != 0; }
-    if (slot_r >= 0) { st.sr = task[slot_r].s; st.bestr = task[slot_r].best; st.alive_r = task[slot_r].run != 0; }
-    if (i < n) summ[i] = lz_probe_summary(P, st);
+    LZ_HIP(hipGetLastError());
+    return 0;
 }
 
-int lzk_probe_hits(LzCtx& c, const LzExtendParams& P, const u64* keys, u64 n, const s32* score_tab, u32* summ)
+// ------------------------------------------------------------------------------------------
+// B2 step 3: the hits of a chunk, which k_fill_hits wrote in discovery order, are (a) scanned independently of
+// the diagonal hash (phase A) and (b) stably partitioned by the high 8 bits of hashedDiag into 256 streams of
+// 8-byte records (lz_lut.hpp), one stream per workgroup of phase B.  One pass over the keys for the partition
+// offsets (k_hist + two small scans), one pass that scans and scatters (k_probe_part): 8 B read + 8 B read +
+// 8 B written per hit, where a radix sort of (key, summary) pairs moved 56.
+#define LZ_PP_TPB    1024
+#define LZ_PP_WAVES  (LZ_PP_TPB / 64)
+#define LZ_PP_ROUNDS 4
+#define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile
+#define LZ_PP_QCAP   1024                            // unfinished scans a tile can queue (more are continued in place)
+#define LZ_NBIN      256
+#define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // bits 8..15 of hashedDiag
+
+// hist[tile][bin]: hits of the tile per partition
+__global__ void __launch_bounds__(LZ_TPB)
+k_hist(const u64* __restrict__ keys, u64 n, u32* __restrict__ hist)
 {
-    if (n == 0) return 0;
-    c.timer.begin("k_probe_hits", c.stream);
-    hipLaunchKernelGGL(k_probe_hits, dim3((unsigned)((n + LZ_PROBE_TPB - 1) / LZ_PROBE_TPB)), dim3(LZ_PROBE_TPB), 0, c.stream,
-                       P, keys, n, score_tab, summ);
+    __shared__ u32 cnt[LZ_NBIN];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * LZ_PP_TILE;
+#pragma unroll
+    for (int r = 0; r < LZ_PP_TILE / LZ_TPB; r++) {
+        const u64 i = base + (u64)r * LZ_TPB + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[LZ_KEY_BIN(keys[i])], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)blockIdx.x * LZ_NBIN + threadIdx.x] = cnt[threadIdx.x];
+}
+// per block of 256 tiles: exclusive prefix down each column, column sums to part[block][bin]
+__global__ void __launch_bounds__(LZ_NBIN)
+k_hist_scan1(u32* __restrict__ hist, u32 ntiles, u32* __restrict__ part)
+{
+    const u32 t0 = blockIdx.x * 256u, t1 = (t0 + 256u < ntiles) ? t0 + 256u : ntiles;
+    u32 acc = 0;
+    for (u32 t = t0; t < t1; t++) { const size_t k = (size_t)t * LZ_NBIN + threadIdx.x; const u32 v = hist[k]; hist[k] = acc; acc += v; }
+    part[(size_t)blockIdx.x * LZ_NBIN + threadIdx.x] = acc;
+}
+// one workgroup: part[block][bin] -> absolute offset of (block, bin); bin_base[0..256]
+__global__ void __launch_bounds__(LZ_NBIN)
+k_hist_scan2(u32* __restrict__ part, u32 nblocks, u32* __restrict__ bin_base)
+{
+    __shared__ u32 tot[LZ_NBIN];
+    u32 acc = 0;
+    for (u32 b = 0; b < nblocks; b++) { const size_t k = (size_t)b * LZ_NBIN + threadIdx.x; const u32 v = part[k]; part[k] = acc; acc += v; }
+    tot[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 a = 0; for (int k = 0; k < LZ_NBIN; k++) { const u32 v = tot[k]; tot[k] = a; a += v; } bin_base[LZ_NBIN] = a; }
+    __syncthreads();
+    const u32 bb = tot[threadIdx.x];
+    bin_base[threadIdx.x] = bb;
+    for (u32 b = 0; b < nblocks; b++) part[(size_t)b * LZ_NBIN + threadIdx.x] += bb;
+}
+
+int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base)
+{
+    const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE), nblocks = (ntiles + 255u) / 256u;
+    c.timer.begin("k_hist", c.stream);
+    hipLaunchKernelGGL(k_hist, dim3(ntiles), dim3(LZ_TPB), 0, c.stream, keys, n, hist);
+    c.timer.end(c.stream);
+    c.timer.begin("k_hist_scan", c.stream);
+    hipLaunchKernelGGL(k_hist_scan1, dim3(nblocks), dim3(LZ_NBIN), 0, c.stream, hist, ntiles, part);
+    hipLaunchKernelGGL(k_hist_scan2, dim3(1), dim3(LZ_NBIN), 0, c.stream, part, nblocks, bin_base);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
 }
 
-// B2 step 4: stable partition of (key, summary) by hashedDiag = key bits 32..47
-int lzk_sort_hits(LzCtx& c, u64* keys_in, u64* keys_out, u32* summ_in, u32* summ_out, u64 n)
+// rank of the lane among the lanes of its wave that hold the same 8-bit key (lower lanes first), the size of
+// that group and whether the lane is its last member; lanes with valid == false are in no group
+__device__ __forceinline__ void lz_match8(u32 key, bool valid, u32 lane, u32& rank, u32& count, bool& last)
 {
-    size_t tmp = 0;
-    LZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, keys_in, keys_out, summ_in, summ_out, (size_t)n,
-                                     32u, 32u + LZ_DIAG_BITS, c.stream));
-    int rc = c.sort_tmp.ensure(tmp);
-    if (rc) return rc;
-    c.timer.begin("rocprim_sort_hits", c.stream);
-    LZ_HIP(rocprim::radix_sort_pairs(c.sort_tmp.p, tmp, keys_in, keys_out, summ_in, summ_out, (size_t)n,
-                                     32u, 32u + LZ_DIAG_BITS, c.stream));
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = ((key >> b) & 1u) != 0;
+        const u64 m = __ballot(bit && valid);
+        peers &= bit ? m : ~m;
+    }
+    const u64 below = (1ull << lane) - 1ull;
+    rank = (u32)__popcll(peers & below);
+    count = (u32)__popcll(peers);
+    last = (peers >> lane) == 1ull;
+}
+// exclusive prefix sum over the first 256 threads of a workgroup (every thread of the workgroup calls it)
+__device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
+    if (tid < 256 && lane == 63) wtot[w] = inc;
+    __syncthreads();
+    u32 pre = 0;
+    if (tid < 256) for (u32 k = 0; k < w; k++) pre += wtot[k];
+    return pre + inc - v;
+}
+
+struct LzPPTask { u32 s; s32 run, best; u32 room, used, nwin; s32 diag; u32 side; };
+struct LzPPShared {
+    LzLutEntry lut[2 * LZ_LUT_ENTRIES];              // MODE 0/1: right table, left table (64 KiB)
+    s32 m16[16];
+    s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64];    // MODE 2: the byte-code scans' tables
+    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition
+    u8  sbin[LZ_PP_TILE];
+    unsigned short wcnt[LZ_PP_WAVES][LZ_NBIN];       // per wave and partition: records so far / start inside the partition
+    u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
+    LzPPTask q[LZ_PP_QCAP]; u32 qn;
+};
+
+template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
+__global__ void __launch_bounds__(LZ_PP_TPB)
+k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n, u32 ntiles,
+             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g, const s32* __restrict__ m16_g,
+             const u32* __restrict__ hist, const u32* __restrict__ part, u64* __restrict__ recs)
+{
+    __shared__ LzPPShared sh;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (MODE < 2) {
+        for (u32 k = tid; k < 2 * LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k];
+        if (tid < 16) sh.m16[tid] = m16_g[tid];
+    } else {
+        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PP_TPB) sh.tab[k] = score_tab_g[k];
+        if (tid < 64) sh.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
+    }
+    const LzLutEntry* lut_r = sh.lut; const LzLutEntry* lut_l = sh.lut + LZ_LUT_ENTRIES;
+    constexpr bool SP = MODE == 1;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const u64 base = (u64)tile * LZ_PP_TILE;
+        const u32 tile_n = (n - base < (u64)LZ_PP_TILE) ? (u32)(n - base) : (u32)LZ_PP_TILE;
+        if (tid == 0) sh.qn = 0;
+        for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN / 2; k += LZ_PP_TPB) reinterpret_cast<u32*>(&sh.wcnt[0][0])[k] = 0;
+        __syncthreads();
+
+        // ---- phase A heads: one window per side for every hit; unfinished scans are queued
+        u64 key[LZ_PP_ROUNDS]; u32 summ[LZ_PP_ROUNDS];
+        u32 usedl[LZ_PP_ROUNDS], usedr[LZ_PP_ROUNDS]; s32 bestl[LZ_PP_ROUNDS], bestr[LZ_PP_ROUNDS];
+        int slotl[LZ_PP_ROUNDS], slotr[LZ_PP_ROUNDS]; u32 alive[LZ_PP_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
+            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
+            const bool valid = li < tile_n;
+            key[r] = valid ? keys[base + li] : 0ull;
+            summ[r] = 0; usedl[r] = usedr[r] = 0; bestl[r] = bestr[r] = 0; slotl[r] = slotr[r] = -1; alive[r] = 0;
+            if (MODE == 2) { if (valid) summ[r] = lz_probe_hit(P, sh.tab, sh.tab8, P.cls8 != 0, key[r]); continue; }
+            s32 diag; LzLutScan L, R;
+            lz_lut_init(key[r], P.tlen, P.qlen, diag, L, R);
+            if (!valid) { L.alive = 0; R.alive = 0; }
+            if (L.alive) lz_lut_window<false, SP>(Q, lut_l, sh.m16, diag, L);
+            if (R.alive) lz_lut_window<true, SP>(Q, lut_r, sh.m16, diag, R);
+            if (L.alive == 1) {
+                const u32 slot = atomicAdd(&sh.qn, 1u);
+                if (slot < LZ_PP_QCAP) { sh.q[slot] = { L.s, L.run, L.best, L.room, L.used, L.nwin, diag, 0u }; slotl[r] = (int)slot; }
+                else while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<false, SP>(Q, lut_l, sh.m16, diag, L);
+            }
+            if (R.alive == 1) {
+                const u32 slot = atomicAdd(&sh.qn, 1u);
+                if (slot < LZ_PP_QCAP) { sh.q[slot] = { R.s, R.run, R.best, R.room, R.used, R.nwin, diag, 1u }; slotr[r] = (int)slot; }
+                else while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<true, SP>(Q, lut_r, sh.m16, diag, R);
+            }
+            usedl[r] = L.used; usedr[r] = R.used; bestl[r] = L.best; bestr[r] = R.best;
+            alive[r] = (L.alive ? 1u : 0u) | (R.alive ? 2u : 0u);
+        }
+        if (MODE < 2) {
+            __syncthreads();
+            // ---- the queued scans, one lane per scan, to the end (or the cap)
+            const u32 nq = sh.qn < (u32)LZ_PP_QCAP ? sh.qn : (u32)LZ_PP_QCAP;
+            for (u32 k = tid; k < nq; k += LZ_PP_TPB) {
+                const LzPPTask t = sh.q[k];
+                LzLutScan S; S.s = t.s; S.run = t.run; S.best = t.best; S.room = t.room; S.used = t.used; S.nwin = t.nwin; S.alive = 1;
+                if (t.side) while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<true, SP>(Q, lut_r, sh.m16, t.diag, S);
+                else        while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<false, SP>(Q, lut_l, sh.m16, t.diag, S);
+                sh.q[k].used = S.used; sh.q[k].best = S.best; sh.q[k].side = S.alive;     // results travel back through the slot
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < LZ_PP_ROUNDS; r++) {
+                if (slotl[r] >= 0) { const LzPPTask& t = sh.q[slotl[r]]; usedl[r] = t.used; bestl[r] = t.best; alive[r] = (alive[r] & ~1u) | (t.side ? 1u : 0u); }
+                if (slotr[r] >= 0) { const LzPPTask& t = sh.q[slotr[r]]; usedr[r] = t.used; bestr[r] = t.best; alive[r] = (alive[r] & ~2u) | (t.side ? 2u : 0u); }
+                u32 s = (usedl[r] & 0xFFu) | ((usedr[r] & 0xFFu) << 8);
+                if (alive[r] || bestl[r] + bestr[r] >= P.min_score) s |= LZ_SUMM_SLOW;
+                summ[r] = s;
+            }
+        }
+
+        // ---- stable partition of the tile's records: rank inside (wave, partition), then the waves' counts are
+        // chained in wave order (= discovery order: a wave holds 256 consecutive hits)
+        u32 lrank[LZ_PP_ROUNDS], bin[LZ_PP_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
+            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
+            const bool valid = li < tile_n;
+            bin[r] = LZ_KEY_BIN(key[r]);
+            u32 rank, count; bool last;
+            lz_match8(bin[r], valid, lane, rank, count, last);
+            const u32 old = sh.wcnt[w][bin[r]];
+            if (valid && last) sh.wcnt[w][bin[r]] = (unsigned short)(old + count);
+            lrank[r] = old + rank;
+        }
+        __syncthreads();
+        u32 tot = 0;
+        if (tid < LZ_NBIN) {
+            for (u32 k = 0; k < LZ_PP_WAVES; k++) { const u32 v = sh.wcnt[k][tid]; sh.wcnt[k][tid] = (unsigned short)tot; tot += v; }
+            sh.gbase[tid] = part[(size_t)(tile >> 8) * LZ_NBIN + tid] + hist[(size_t)tile * LZ_NBIN + tid];
+        }
+        const u32 ts = lz_exscan256(tot, sh.wtot);
+        if (tid < LZ_NBIN) sh.tstart[tid] = ts;
+        if (tid == 0) sh.tstart[LZ_NBIN] = tile_n;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
+            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
+            if (li < tile_n) {
+                const u32 pos = sh.tstart[bin[r]] + sh.wcnt[w][bin[r]] + lrank[r];
+                sh.stage[pos] = lz_hit_record(key[r], summ[r]);
+                sh.sbin[pos] = (u8)bin[r];
+            }
+        }
+        __syncthreads();
+        for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
+            const u32 b = sh.sbin[k];
+            recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = sh.stage[k];
+        }
+        __syncthreads();
+    }
+}
+
+int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
+                   const s32* score_tab, const LzLutEntry* lut, const s32* m16, const u32* hist, const u32* part, u64* recs)
+{
+    if (n == 0) return 0;
+    const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE);
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
+    const u32 grid = ntiles < (u32)cus ? ntiles : (u32)cus;     // one 1024-thread workgroup per CU (the tables fill most of its LDS)
+    c.timer.begin("k_probe_part", c.stream);
+    if (mode == 0)      hipLaunchKernelGGL(k_probe_part<0>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
+    else if (mode == 1) hipLaunchKernelGGL(k_probe_part<1>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
+    else                hipLaunchKernelGGL(k_probe_part<2>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
     c.timer.end(c.stream);
+    LZ_HIP(hipGetLastError());
     return 0;
 }
 
-// B2 step 5 (phase B): one lane per hash bucket
-#define LZ_EXT_TPB 64
-__global__ void __launch_bounds__(LZ_EXT_TPB)
-k_extend(LzExtendParams P, const u64* __restrict__ keys, const u32* __restrict__ summ, u32 n,
-         u32* __restrict__ diag_end, const s32* __restrict__ score_tab_g,
-         LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap, u64* __restrict__ counters)
+// ------------------------------------------------------------------------------------------
+// B2 step 4 (phase B): one workgroup per partition (256 buckets), one lane per bucket with diagEnd[h] in a
+// register.  The partition's records arrive in discovery order; a tile of them is loaded with coalesced reads,
+// dealt out to the buckets inside LDS (counting sort by the record's low hash bits: counts, offsets, placement),
+// and every lane then walks its own short list in order (lz_settle_record).
+#define LZ_ST_TPB    256
+#define LZ_ST_TILE   2048
+#define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
+__global__ void __launch_bounds__(LZ_ST_TPB)
+k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__ bin_base, u32* __restrict__ diag_end,
+         const s32* __restrict__ score_tab_g, LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap,
+         u64* __restrict__ counters)
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
-    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_EXT_TPB) tab[k] = score_tab_g[k];
-    __syncthreads();
-    const u32 h = blockIdx.x * LZ_EXT_TPB + threadIdx.x;
-    // the lane's bucket = the run of keys whose bits 32..47 equal h (the array is partitioned by them):
-    // two binary searches, 2 x 28 dependent loads once per launch instead of a pass over all keys
-    u32 i0 = 0, i1 = 0;
-    {
-        u32 a = 0, b = n;
-        while (a < b) { const u32 m = a + ((b - a) >> 1); if ((u32)((keys[m] >> 32) & (LZ_DIAG_SIZE - 1)) < h) a = m + 1; else b = m; }
-        i0 = a; b = n;
-        while (a < b) { const u32 m = a + ((b - a) >> 1); if ((u32)((keys[m] >> 32) & (LZ_DIAG_SIZE - 1)) <= h) a = m + 1; else b = m; }
-        i1 = a;
-    }
+    __shared__ u64 rec[LZ_ST_TILE];
+    __shared__ unsigned short list[LZ_ST_TILE];
+    __shared__ u32 cnt[4][LZ_NBIN];
+    __shared__ u32 wtot[4];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    for (int k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_ST_TPB) tab[k] = score_tab_g[k];
+    const u32 h = blockIdx.x * LZ_NBIN + tid;
+    u32 dend = diag_end[h];
     u64 n_ext = 0, n_bp = 0;
-    if (i0 < i1) {
-        u32 d = lz_extend_bucket(P, tab, keys, summ, i0, i1, diag_end[h], n_ext, n_bp,
-            [&](const LzHspRec& r) {
-                u32 slot = atomicAdd(out_count, 1u);
-                if (slot < out_cap) out[slot] = r;
-            });
-        diag_end[h] = d;
+    const u32 r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
+    auto emit = [&](const LzHspRec& r) { const u32 slot = atomicAdd(out_count, 1u); if (slot < out_cap) out[slot] = r; };
+    // a wave owns a quarter of the tile (consecutive records), which it takes 64 at a time
+    u64 x[LZ_ST_ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane; x[rr] = ((u64)r0 + li < (u64)r1) ? recs[(size_t)r0 + li] : 0ull; }
+    for (u32 t0 = r0; t0 < r1; t0 += LZ_ST_TILE) {
+        const u32 nt = (r1 - t0 < (u32)LZ_ST_TILE) ? r1 - t0 : (u32)LZ_ST_TILE;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt[k][tid] = 0;
+        __syncthreads();
+        u32 slot[LZ_ST_ROUNDS], k8[LZ_ST_ROUNDS];
+#pragma unroll
+        for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
+            const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane;
+            k8[rr] = LZ_REC_LOW8(x[rr]); slot[rr] = 0;
+            if (li < nt) { rec[li] = x[rr]; slot[rr] = atomicAdd(&cnt[w][k8[rr]], 1u); }
+        }
+        __syncthreads();
+        // offsets: bucket-major, then wave order inside a bucket
+        const u32 c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+        const u32 mine = c0 + c1 + c2 + c3;
+        const u32 beg = lz_exscan256(mine, wtot);
+        cnt[0][tid] = beg; cnt[1][tid] = beg + c0; cnt[2][tid] = beg + c0 + c1; cnt[3][tid] = beg + c0 + c1 + c2;
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
+            const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane;
+            if (li < nt) list[cnt[w][k8[rr]] + slot[rr]] = (unsigned short)li;
+        }
+        __syncthreads();
+        // the next tile's records are requested before this one is walked
+        if (t0 + LZ_ST_TILE < r1) {
+#pragma unroll
+            for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane; x[rr] = ((u64)t0 + LZ_ST_TILE + li < (u64)r1) ? recs[(size_t)t0 + LZ_ST_TILE + li] : 0ull; }
+        }
+        // Records a wave placed in the same step may sit in any order among themselves (the slots come from
+        // LDS atomics): the list is put in ascending tile order, which is discovery order, by an insertion pass
+        // (it is sorted already but for such neighbours).
+        for (u32 p = beg + 1; p < beg + mine; p++) {
+            const unsigned short v = list[p];
+            u32 q = p;
+            while (q > beg && list[q - 1] > v) { list[q] = list[q - 1]; q--; }
+            list[q] = v;
+        }
+        for (u32 p = beg; p < beg + mine; p++)
+            lz_settle_record(P, tab, rec[list[p]], h, dend, n_ext, n_bp, emit);
+        __syncthreads();
     }
-    // wave-level reduction of the work counters
+    diag_end[h] = dend;
     for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);
         if (n_bp)  atomicAdd((unsigned long long*)&counters[1], (unsigned long long)n_bp);
     }
 }
 
-int lzk_extend(LzCtx& c, const LzExtendParams& P, const u64* keys, const u32* summ, u32 n, u32* diag_end,
+int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
-    c.timer.begin("k_extend", s);
-    hipLaunchKernelGGL(k_extend, dim3(LZ_DIAG_SIZE / LZ_EXT_TPB), dim3(LZ_EXT_TPB), 0, s,
-                       P, keys, summ, n, diag_end, score_tab, out, out_count, out_cap, counters);
+    c.timer.begin("k_settle", s);
+    hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;

@@ -59,7 +59,7 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdo
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window",
-           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order"]
+           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode"]
 
 
 class LzGpuError(RuntimeError):
@@ -212,6 +212,12 @@ class Lib:
 
     def set_bucket_owner(self, n_owners, owner):
         self._check(self._f("set_bucket_owner")(C.c_uint32(n_owners), C.c_uint32(owner)), "lzgpu_set_bucket_owner")
+
+    def last_scan_mode(self):
+        return int(self.L.lzgpu_last_scan_mode())
+
+    def set_scan_mode(self, min_mode):
+        self._check(self.L.lzgpu_set_scan_mode(C.c_int(min_mode)), "lzgpu_set_scan_mode")
 
     def last_hsp_order(self, n):
         """(n, 2) uint64 sort words of the HSPs the last search returned (see include/lzgpu.h)"""

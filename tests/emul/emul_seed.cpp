@@ -12,6 +12,7 @@
 #include <vector>
 #include "../../lastz_amd/csrc/lz_common.hpp"
 #include "../../lastz_amd/csrc/lz_host.hpp"
+#include "../../lastz_amd/csrc/lz_lut.hpp"
 
 struct Emul {
     std::vector<u8> traw, tcode;   // with LZ_SEQ_PAD either side
@@ -21,6 +22,7 @@ struct Emul {
     std::vector<u32> wstart, wpos;
     u64 hit_cap = 1ull << 28;
     lz_counters cnt = {};
+    int last_scan_mode = -1;
 };
 static Emul E;
 
@@ -117,26 +119,68 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     s32 tab8[64];
     for (int k = 0; k < 64; k++) tab8[k] = tab[(k >> 3) * LZ_NCLASS + (k & 7)];
     u64 n_ext = 0, n_bp = 0;
+    // 2-bit codes + special masks as k_pack2 builds them, occurrence sets as k_byte_presence does
+    auto pack2 = [](const std::vector<u8>& code /*with LZ_SEQ_PAD*/, u32 len, std::vector<u8>& two, std::vector<u8>& spc) {
+        const size_t nmask = ((size_t)len + 2 * LZ_PAD2 + 7) / 8 + 16;
+        two.assign(nmask * 2 + 32, 0); spc.assign(nmask + 32, 0xFF);
+        for (size_t j = 0; j < nmask; j++) {
+            u32 bits = 0, m = 0;
+            for (int k = 0; k < 8; k++) {
+                const s64 i = (s64)j * 8 - LZ_PAD2 + k;
+                const u32 c = (i >= -(s64)LZ_SEQ_PAD && i < (s64)len + LZ_SEQ_PAD) ? code[(size_t)(i + LZ_SEQ_PAD)] : (u32)LZ_CODE_INVALID;
+                if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_CODE_BITS(c) << (2 * k);
+            }
+            spc[j] = (u8)m; two[2 * j] = (u8)bits; two[2 * j + 1] = (u8)(bits >> 8);
+        }
+    };
+    std::vector<u8> t2, tsp, q2, qsp;
+    pack2(E.tcode, E.tlen, t2, tsp); pack2(qcode, qlen, q2, qsp);
+    u8 tocc[256] = { 0 }, qocc[256] = { 0 }; bool tspecial = false, qspecial = false;
+    for (u32 i = 0; i < E.tlen; i++) { const u8 b = E.traw[LZ_SEQ_PAD + i]; tocc[b] = 1; if (E.ctb[b] < 0) tspecial = true; }
+    for (u32 i = 0; i < qlen; i++) { const u8 b = a->query[i]; qocc[b] = 1; if (E.ctb[b] < 0) qspecial = true; }
+    s32 M4[16] = { 0 };
+    int scan_mode = 2;
+    if (lzh_lut_eligible(a->sub, E.ctb, tocc, qocc, a->xdrop, M4)) scan_mode = (tspecial || qspecial) ? 1 : 0;
+    if (const char* f = getenv("EMUL_SCAN_MODE")) { const int v = atoi(f); if (scan_mode < 2 && v > scan_mode) scan_mode = v > 2 ? 2 : v; }
+    E.last_scan_mode = scan_mode;
+    std::vector<LzLutEntry> lut(2 * LZ_LUT_ENTRIES);
+    if (scan_mode < 2) lzh_lut_build(M4, a->xdrop, lut.data());
+    LzLutParams Q; Q.t2 = t2.data(); Q.q2 = q2.data(); Q.tsp = tsp.data(); Q.qsp = qsp.data(); Q.xdrop = a->xdrop;
     for (auto& ch : chunks) {
         std::vector<u64> keys(ch.nh);
         for (u32 i = ch.i0; i < ch.i1; i++)
             if (cnt[i]) lz_fill_hits_at(qc, lo + i + 1, E.sd, E.wstart.data(), E.wpos.data(), keys.data() + (off[i] - ch.base));
         if (!a->extend) { for (u64 k : keys) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); } continue; }
-        // phase A on the unsorted hits, then the (key, summary) pairs are partitioned together
-        std::vector<std::pair<u64, u32>> kv(keys.size());
-        for (size_t i = 0; i < keys.size(); i++) kv[i] = { keys[i], lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]) };
-        std::stable_sort(kv.begin(), kv.end(), [](auto& x, auto& y) { return ((x.first >> 32) & 0xFFFF) < ((y.first >> 32) & 0xFFFF); });
-        std::vector<u32> summ(keys.size());
-        for (size_t i = 0; i < keys.size(); i++) { keys[i] = kv[i].first; summ[i] = kv[i].second; }
-        u64 nk = keys.size();
-        for (u64 i = 0; i <= nk; i++) {
-            s32 bp = (i == 0) ? -1 : (s32)((keys[i - 1] >> 32) & 0xFFFF), b = (i == nk) ? (s32)LZ_DIAG_SIZE : (s32)((keys[i] >> 32) & 0xFFFF);
-            for (s32 w = bp + 1; w <= b; w++) bstart[w] = (u32)i;
+        // phase A on the hits in discovery order (look-up-table scans on 2-bit codes when the matrix allows it,
+        // k_probe_part<0/1>, else the byte-code scans, <2>), 8-byte records, stable partition by the high 8 hash
+        // bits; phase B (k_settle): per partition, tiles of LZ_ST_TILE records are dealt out to the 256 buckets
+        // and every bucket walks its list in tile order
+        std::vector<u64> rec(keys.size());
+        for (size_t i = 0; i < keys.size(); i++) {
+            u32 sm;
+            if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, M4, P.tlen, P.qlen, P.min_score, keys[i]);
+            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, M4, P.tlen, P.qlen, P.min_score, keys[i]);
+            else                     sm = lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]);
+            rec[i] = lz_hit_record(keys[i], sm);
         }
-        for (u32 h = 0; h < LZ_DIAG_SIZE; h++) {
-            if (bstart[h] == bstart[h + 1]) continue;
-            diag_end[h] = lz_extend_bucket(P, tab, keys.data(), summ.data(), bstart[h], bstart[h + 1], diag_end[h], n_ext, n_bp,
-                                           [&](const LzHspRec& r) { recs.push_back(r); });
+        std::vector<size_t> ord(keys.size());
+        for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return ((keys[x] >> 40) & 0xFF) < ((keys[y] >> 40) & 0xFF); });
+        size_t p0 = 0;
+        for (u32 bin = 0; bin < 256; bin++) {
+            size_t p1 = p0;
+            while (p1 < ord.size() && ((keys[ord[p1]] >> 40) & 0xFF) == bin) p1++;
+            for (size_t t0 = p0; t0 < p1; t0 += 2048) {
+                const size_t t1 = std::min(p1, t0 + 2048);
+                std::vector<std::vector<u64>> lists(256);
+                for (size_t k = t0; k < t1; k++) lists[LZ_REC_LOW8(rec[ord[k]])].push_back(rec[ord[k]]);
+                for (u32 b = 0; b < 256; b++) {
+                    const u32 h = bin * 256 + b;
+                    for (u64 r : lists[b])
+                        lz_settle_record(P, tab, r, h, diag_end[h], n_ext, n_bp, [&](const LzHspRec& x) { recs.push_back(x); });
+                }
+            }
+            p0 = p1;
         }
     }
     E.cnt.words += words; E.cnt.raw_hits += off[n]; E.cnt.extensions += n_ext; E.cnt.bp_extended += n_bp;
@@ -156,6 +200,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     return 0;
 }
 extern "C" void emul_free(void* p) { free(p); }
+extern "C" int emul_last_scan_mode() { return E.last_scan_mode; }
 
 // Self-test of the three block scanners on random class codes: the masked general scan
 // (lz_scan_left16/right16 without the 8x8 table), the whole-block byte scan and the 4-bit scan must agree

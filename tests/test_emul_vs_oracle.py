@@ -109,3 +109,50 @@ def test_chunk_planner_splits_inside_a_block(em):
     em.table_prepare(np.tile(unit, 4000), sd, lzo.upper_nuc_to_bits())
     with pytest.raises(lzgpu.NotHandled):                  # one position alone exceeds the capacity
         em.seed_hit_search(masked, q=q)
+
+
+def _mode(em):
+    em.L.emul_last_scan_mode.restype = C.c_int
+    return em.L.emul_last_scan_mode()
+
+
+def test_scan_modes_cover_lut_and_byte_code_paths(em, monkeypatch):
+    """which phase-A scanner a search takes: look-up tables on 2-bit codes without (0) / with (1) special-byte
+    masks, or the byte-code scans (2); every forced downgrade must give the same answer"""
+    t, q = H.load_case("synth200k")
+    _check(em, t, q, cap=50000)
+    assert _mode(em) == 0
+    ta, qa = H.load_case("adversarial")
+    _check(em, ta, qa, cap=5000)
+    assert _mode(em) == 1
+    for forced in ("1", "2"):
+        monkeypatch.setenv("EMUL_SCAN_MODE", forced)
+        _check(em, t, q, cap=50000)
+        assert _mode(em) == int(forced)
+        _check(em, ta, qa, cap=5000)
+    monkeypatch.delenv("EMUL_SCAN_MODE")
+    qr = q.copy(); qr[::997] = ord("R")                    # an IUPAC byte scores fillScore (-100): not a scan terminator
+    _check(em, t, qr, cap=50000)
+    assert _mode(em) == 2
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lut_scans_with_dense_specials_and_short_sequences(em, seed):
+    """special bytes every few bases around the seeds, sequence ends inside the windows, several xDrop values:
+    the window limits (hard end, special base consumed, partial groups) of lz_lut_window"""
+    rng = np.random.default_rng(seed)
+    t, q = seqio.synth_pair(30000, 24000, seed=100 + seed, block_min=300, block_max=2500)
+    t = t.copy(); q = q.copy()
+    for arr in (t, q):
+        n = len(arr)
+        idx = rng.integers(0, n, n // 40)
+        arr[idx] |= 0x20                                     # scattered lower case
+        for s in rng.integers(0, n - 50, 60):
+            arr[s:s + int(rng.integers(1, 40))] = ord("N")   # N runs
+    _, masked = H.scoring()
+    for xd in (910, 400, 250):
+        _check(em, t, q, masked=masked, xdrop=xd, hsp_threshold=2000, cap=30000)
+        assert _mode(em) == 1
+    _check(em, t[:300], q[:200], pattern="11111111", wt=0, hsp_threshold=800)          # everything within reach of an end
+    _check(em, t, q, xdrop=249, hsp_threshold=1500)         # two bases after a maximum set inside a group can lose 250 > xDrop: not eligible
+    assert _mode(em) == 2

@@ -136,6 +136,55 @@ def test_matrix_with_more_than_8_classes(gpu):
     _same_hsps(gpu, tab, q, masked)                         # and back: the class tables are re-derived
 
 
+def test_scan_modes_lut_and_byte_code(gpu):
+    """phase A: look-up-table scans on 2-bit codes without (0) / with (1) special-byte masks, byte-code scans
+    (2); each forced downgrade gives the oracle's answer too (src/seed_search.c:2623-2632, 2684-2693)"""
+    _, masked = H.scoring()
+    t, q = H.load_case("synth200k")
+    ta, qa = H.load_case("adversarial")
+    try:
+        for forced in (0, 1, 2):
+            gpu.set_scan_mode(forced)
+            tab = _prep(gpu, t)
+            for _, _, qq in H.strands(q):
+                _same_hsps(gpu, tab, qq, masked)
+                assert gpu.last_scan_mode() == forced
+            tab = _prep(gpu, ta)
+            gpu.set_hit_capacity(5000)
+            for _, _, qq in H.strands(qa):
+                _same_hsps(gpu, tab, qq, masked)
+                assert gpu.last_scan_mode() == max(forced, 1)
+            gpu.set_hit_capacity(1 << 28)
+        gpu.set_scan_mode(0)
+        qr = q.copy(); qr[::997] = ord("R")                # fillScore (-100) does not end a scan: byte-code scans
+        tab = _prep(gpu, t)
+        _same_hsps(gpu, tab, qr, masked)
+        assert gpu.last_scan_mode() == 2
+    finally:
+        gpu.set_scan_mode(0); gpu.set_hit_capacity(1 << 28)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_lut_scans_dense_specials_short_sequences(gpu, seed):
+    """special bytes every few bases, sequence ends inside the scan windows, several xDrop values"""
+    rng = np.random.default_rng(seed)
+    t, q = seqio.synth_pair(300000, 240000, seed=100 + seed, block_min=300, block_max=2500)
+    t = t.copy(); q = q.copy()
+    for arr in (t, q):
+        n = len(arr)
+        arr[rng.integers(0, n, n // 40)] |= 0x20
+        for s in rng.integers(0, n - 50, 600):
+            arr[s:s + int(rng.integers(1, 40))] = ord("N")
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    for xd in (910, 400, 250, 249):
+        for _, _, qq in H.strands(q):
+            _same_hsps(gpu, tab, qq, masked, xdrop=xd, hsp_threshold=2000)
+        assert gpu.last_scan_mode() == (1 if xd >= 250 else 2)
+    tab = _prep(gpu, t[:300], "11111111", 0)
+    _same_hsps(gpu, tab, q[:200], masked, hsp_threshold=800)
+
+
 def test_bucket_ownership_sharding_inside_one_query(gpu):
     """the hashed-diagonal buckets dealt out to n processes; merged lists == the single list"""
     from lastz_amd import shard
@@ -190,10 +239,10 @@ def test_two_mbp_pair_and_capacity_invariance(gpu):
 
 
 def test_full_size_properties(gpu):
-    """BASELINE.json config 2 size class (scaled to keep the GPU tier short): properties that do not
+    """BASELINE.json configs[1] size (50 Mbp x 50 Mbp, one strand): properties that do not
     need the oracle -- determinism, chunk-capacity invariance, every HSP re-scores to its score on
     the host, HSPs arrive in discovery-compatible order, counters obey H >= E >= HSPs."""
-    t, q = seqio.synth_pair(20_000_000, 20_000_000, seed=4)
+    t, q = seqio.synth_pair(50_000_000, 50_000_000, seed=4)
     sub, masked = H.scoring()
     _prep(gpu, t)
     gpu.counters_reset()
