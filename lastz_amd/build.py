@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblzgpu.so")
 SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "lz_host.cpp", "lz_gapped_host.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("LZGPU_CXXFLAGS", "").split()
 
 
 def _stale(obj, srcs):
@@ -19,7 +19,9 @@ def _stale(obj, srcs):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    tag = os.environ.get("LZGPU_BUILD_TAG", "")          # variant builds (profiling switches): liblzgpu_<tag>.so, picked up with LZGPU_LIB
+    out = OUT if not tag else os.path.join(HERE, "liblzgpu_%s.so" % tag)
+    objdir = os.path.join(HERE, "build" if not tag else "build_" + tag)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     headers.append(os.path.join(HERE, "..", "include", "lzgpu.h"))
@@ -38,12 +40,12 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs
+    if force or procs or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

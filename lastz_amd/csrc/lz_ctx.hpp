@@ -77,7 +77,7 @@ struct LzCtx {
     DevBuf recs[2], bin_base[2];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
                                     // phase B of a chunk runs while the next chunk is filled / scanned / partitioned
     DevBuf hist, hist_part;         // per-tile partition histogram and its block sums
-    DevBuf lut, m16;                // phase-A tables (lz_lut.hpp)
+    DevBuf lut;                     // phase-A tables (lz_lut.hpp)
     DevBuf sort_tmp, scan_tmp;
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
     DevBuf score_tab;               // [32*32] s32
@@ -116,6 +116,6 @@ struct LzLutParams; struct LzLutEntry;
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
 int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base);
 int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                   const s32* score_tab, const LzLutEntry* lut, const s32* m16, const u32* hist, const u32* part, u64* recs);
+                   const s32* score_tab, const LzLutEntry* lut, const u32* hist, const u32* part, u64* recs);
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

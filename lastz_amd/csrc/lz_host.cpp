@@ -117,11 +117,24 @@ u32 lzh_small_classes(const u8 rowc[256], const u8 colc[256])
     return 1;
 }
 
-// ---- phase-A look-up tables
+// ---- phase-A look-up tables (lz_lut.hpp)
+// F[x][w]: the score of a base pair whose Gray codes differ by x, the target's having low bit w
+static int lut_classes(const s32 M4[16], s32 F[4][2])
+{
+    bool have[4][2] = { { false } };
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+        const int ga = LZ_GRAY(a), gb = LZ_GRAY(b), x = ga ^ gb, w = ga & 1;
+        if (have[x][w] && F[x][w] != M4[4 * a + b]) return 0;       // not invariant under complementing both bases
+        have[x][w] = true; F[x][w] = M4[4 * a + b];
+    }
+    return 1;
+}
+
 int lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], const u8 qocc[256], s32 xdrop, s32 M4[16])
 {
     if (xdrop < 0 || xdrop > 15000) return 0;
     // plain bytes: the score depends on the 2-bit codes only (among the bytes that occur)
+    s32 lo = 0;
     for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
         bool have = false; s32 v = 0;
         for (int r = 1; r < 256; r++) {
@@ -136,9 +149,12 @@ int lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], 
         if (!have) {                                            // the pair never occurs: any representative will do
             for (int r = 1; r < 256 && !have; r++) if (ctb[r] == a) for (int c = 1; c < 256 && !have; c++) if (ctb[c] == b) { v = sub[256 * r + c]; have = true; }
         }
-        if (v > 5000 || v < -5000) return 0;
+        if (v > 127 || v < -127) return 0;                      // scores travel as signed bytes
+        if (v < lo) lo = v;
         M4[4 * a + b] = v;
     }
+    s32 F[4][2];
+    if (!lut_classes(M4, F)) return 0;
     // special bytes end a scan: whatever they meet scores below -xDrop
     for (int r = 0; r < 256; r++) {
         if (!tocc[r]) continue;
@@ -147,30 +163,31 @@ int lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], 
             if ((ctb[r] < 0 || ctb[c] < 0) && (s64)sub[256 * r + c] >= -(s64)xdrop) return 0;
         }
     }
-    // no three-base group loses more than xDrop from a maximum set inside the group
-    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
-        const s32 d1 = -M4[i], d2 = -(M4[i] + M4[j]);           // drop over the next base / the next two bases
-        if (d1 > xdrop || d2 > xdrop) return 0;
-    }
+    // no four-base group loses more than xDrop over the (at most three) bases after a maximum set inside the group
+    if (-3 * lo > xdrop) return 0;
     return 1;
 }
 
 void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab)
 {
+    s32 F[4][2] = { { 0 } };
+    lut_classes(M4, F);
     for (int dir = 0; dir < 2; dir++)                           // 0: right scans (low bases first), 1: left scans (high bases first)
         for (u32 idx = 0; idx < LZ_LUT_ENTRIES; idx++) {
-            const u32 tf = idx >> 6, qf = idx & 63u;
-            s32 p = 0, minp = 0x7FFFFFFF, maxp = -0x7FFFFFFF;
-            for (u32 b = 0; b < 3; b++) {
-                const u32 sh = dir == 0 ? 2u * b : 2u * (2u - b);
-                p += M4[(((tf >> sh) & 3u) << 2) | ((qf >> sh) & 3u)];
+            const u32 xb = idx & 0xFFu, wn = idx >> 8;
+            s32 p = 0, minp = 0x7FFFFFFF, maxp = -0x7FFFFFFF; u32 sc = 0;
+            for (u32 k = 0; k < 4; k++) {
+                const u32 j = dir == 0 ? k : 3u - k;            // base of the byte consumed k-th
+                const s32 v = F[(xb >> (2 * j)) & 3u][(wn >> j) & 1u];
+                sc |= (u32)(u8)(int8_t)v << (8 * k);
+                p += v;
                 if (p < minp) minp = p;
                 if (p > maxp) maxp = p;
             }
             const u32 A = minp < 0 ? (u32)(-minp) : 0u;
-            const s32 B = xdrop - (maxp > 0 ? maxp : 0);        // the margin never exceeds xDrop; -15000 <= B <= 15000 (lzh_lut_eligible)
+            const s32 B = xdrop - (maxp > 0 ? maxp : 0);        // the margin never exceeds xDrop
             tab[dir * LZ_LUT_ENTRIES + idx].ab = A | ((u32)(B & 0xFFFF) << 16);
-            tab[dir * LZ_LUT_ENTRIES + idx].c = p;
+            tab[dir * LZ_LUT_ENTRIES + idx].sc = sc;
         }
 }
 

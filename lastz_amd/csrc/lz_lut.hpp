@@ -1,175 +1,191 @@
 // lz_lut.hpp -- phase A of the seed stage on 2-bit codes: the two X-drop scans of a raw hit
-// (xdrop_extend_seed_hit loops 1 and 2, src/seed_search.c:2623-2632, 2684-2693) advance THREE bases per
+// (xdrop_extend_seed_hit loops 1 and 2, src/seed_search.c:2623-2632, 2684-2693) advance FOUR bases per
 // step through a look-up table held in LDS, instead of one base per step.
 //
 // Why this is exact.  Let run / best be the reference's running and best score of one scan and
 // m = run - best + xDrop >= 0 its margin (the loop test "run >= best - xDrop" is m >= 0).  For the next
-// three bases with prefix sums P1,P2,P3 (P3 = C), minP = min Pj, maxP = max Pj:
-//   * the scan stops inside the group  <=>  m + minP < 0, PROVIDED no three-base group can lose more than
-//     xDrop from a prefix maximum set inside the same group (checked when the table is built: the "internal
-//     drawdown" of every group, i.e. the loss over the one or two bases after a maximum, is <= xDrop; with HOXD70 it is
-//     at most 250 against xDrop 910);
-//   * otherwise best' = max(best, run + maxP), run' = run + C, i.e. m' = min(m, xDrop - maxP) + C.
-// An entry therefore holds A = max(0,-minP), B' = xDrop - max(maxP,0) (m never exceeds xDrop) and C; a step is one LDS read, one compare
-// and three integer operations for three bases.  The group in which the scan stops (or which is cut by the
-// end of the sequences / a byte that is not A,C,G,T) is walked base by base with the reference's own loop.
+// four bases with prefix sums P1..P4 (P4 = C), minP = min Pj, maxP = max Pj:
+//   * the scan stops inside the group  <=>  m + minP < 0, PROVIDED no group can lose more than xDrop from a
+//     prefix maximum set inside the same group (checked when the table is built: the loss over the one, two or
+//     three bases after a maximum is <= xDrop; with HOXD70 it is at most 375 against xDrop 910);
+//   * otherwise best' = max(best, run + maxP), run' = run + C, i.e. m' = min(m, xDrop - max(maxP,0)) + C.
+// An entry holds A = max(0,-minP), B' = xDrop - max(maxP,0) and the four scores as signed bytes (C is their
+// sum: one v_dot4 adds it); a step is one LDS read, two compares and a handful of integer operations for four
+// bases, WITHOUT any branch: a lane whose scan has stopped keeps its state through selects, so that the wave
+// executes straight-line code.  The group in which the scan stops (or which is cut by the end of the
+// sequences / a byte that is not A,C,G,T) is then walked base by base with the reference's own loop.
+//
+// Table index.  The 2-bit codes are stored Gray-coded (A=0, C=1, G=3, T=2) so that for every matrix that is
+// invariant under complementing both bases (M[a][b] == M[3-a][3-b]: every strand-symmetric DNA matrix, HOXD70
+// included) the score depends on x = t ^ q and the low bit of t only: 3 bits per base, 12 bits per group of
+// four, 4096 entries of 8 bytes per scan direction.  Four bases are one byte of the code stream, so that a
+// group's index is one byte of (t ^ q) and one nibble of the compressed low-bit plane of t.
 //
 // Bytes outside the 2-bit alphabet ("specials": lower case, N, the NUL between partitions, ...) are kept in a
 // separate 1-bit-per-base mask.  The LUT path is only taken when every special byte that OCCURS in the two
 // sequences scores below -xDrop against everything that occurs in the other one: the reference's scan then
 // consumes that base and stops without raising its best, which is what lz_lut_window does when it meets a
-// mask bit.  (lzh_lut_eligible checks this; any other matrix runs the byte-code scans of lz_common.hpp.)
+// mask bit.  (lzh_lut_eligible checks all of this; any other matrix runs the byte-code scans of lz_common.hpp.)
 //
 // The functions here are the per-lane device logic (LZ_HD: also compiled for the host by tests/emul).
 #pragma once
 #include "lz_common.hpp"
 
 #define LZ_PAD2         128          // padding bases in front of base 0 in the 2-bit and mask arrays (and >= that after the end)
-#define LZ_LUT_ENTRIES  4096         // 3 bases x (2 + 2) bits
-#define LZ_LUT_WIN_G    20           // groups per 16-byte window
+#define LZ_LUT_ENTRIES  4096         // 4 bases x 3 bits
+#define LZ_LUT_WIN_G    15           // groups per 16-byte window
 #define LZ_LUT_WIN_B    60           // bases per window
 #define LZ_LUT_MAXWIN   3            // windows per scan (180 bases); a scan still alive after that makes the hit SLOW
+#define LZ_GRAY(c)      ((c) ^ ((c) >> 1))      // 2-bit code as stored in the phase-A arrays
 
-struct LzLutEntry { u32 ab; s32 c; };           // ab = A (u16) | B' (s16) << 16
+struct LzLutEntry { u32 ab; u32 sc; };          // ab = A (u16) | B' (s16) << 16; sc = the four scores, signed bytes, first consumed in byte 0
 
 struct LzLutParams {
-    const u8* t2; const u8* q2;                   // 2-bit codes: base i at bits 2*((i+PAD2)&3) of byte (i+PAD2)>>2
-    const u8* tsp; const u8* qsp;                 // special masks: base i at bit (i+PAD2)&7 of byte (i+PAD2)>>3 (NULL: no specials)
+    const u8* t2; const u8* q2;                   // Gray 2-bit codes: base i at bits 2*((i+PAD2)&3) of byte (i+PAD2)>>2
+    const u8* tsp; const u8* qsp;                 // special masks: base i at bit (i+PAD2)&7 of byte (i+PAD2)>>3
     s32 xdrop;
 };
 
-struct LzLutScan { u32 s; s32 run, best; u32 room, used, alive, nwin; };
+struct LzLutScan { u32 s; s32 run, best; u32 room, used, alive, nwin; };   // alive: 0 stopped, 1 goes on, 2 undecided (-> SLOW)
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define LZ_WAVE_NONE(x) (__builtin_amdgcn_ballot_w64((bool)(x)) == 0ull)
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-LZ_HD u32 lz_ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
-LZ_HD u32 lz_clz64(u64 x) { return (u32)__builtin_clzll(x); }
+LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return __builtin_amdgcn_sdot4((int)a, 0x01010101, acc, false); }
+LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k)    // (byte k of hi_src) << 8 | byte k of lo_src
+{ return __builtin_amdgcn_perm(hi_src, lo_src, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k); }
+#define LZ_UNROLL_ALL _Pragma("unroll")
 #else
-#define LZ_WAVE_NONE(x) (!(x))
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { sh &= 31u; return sh ? (lo >> sh) | (hi << (32u - sh)) : lo; }
+LZ_HD s32 lz_sdot4(u32 a, s32 acc) { for (int k = 0; k < 4; k++) acc += (s32)(int8_t)(a >> (8 * k)); return acc; }
+LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k) { return (((hi_src >> (8 * k)) & 0xFFu) << 8) | ((lo_src >> (8 * k)) & 0xFFu); }
+#define LZ_UNROLL_ALL
+#endif
 LZ_HD u32 lz_ctz64(u64 x) { return (u32)__builtin_ctzll(x); }
 LZ_HD u32 lz_clz64(u64 x) { return (u32)__builtin_clzll(x); }
-#endif
 
-// six bits starting at a compile-time bit position of a 128-bit window (position order: lowest base in the low bits)
-LZ_HD u32 lz_lut_field(const u32 w[4], int bit)
+// the raw bytes of one window: 16 bytes of each code stream (+ 16 bytes of each special mask)
+template <bool SPECIAL> struct LzLutRaw { LzVec16 tv, qv, tm, qm; };
+template <> struct LzLutRaw<false> { LzVec16 tv, qv; };
+// group g of a window is byte g of the aligned stream (RIGHT: base s at bit 0) / byte 14 - g (LEFT: base s-1 at
+// bits 118-119: the 16 bytes that end with the byte of base s-1, shifted right by 2r' + 2 bits)
+template <bool RIGHT, bool SPECIAL>
+LZ_HD void lz_lut_fetch(const LzLutParams& P, u32 s_, s32 diag, LzLutRaw<SPECIAL>& raw)
 {
-    const int wd = bit >> 5, off = bit & 31;
-    u32 v = w[wd] >> off;
-    if (off > 26) v |= w[wd + 1] << (32 - off);
-    return v & 63u;
+    const s64 s = (s64)s_, sq = s - (s64)diag;
+    if (RIGHT) { raw.tv = lz_load16(P.t2 + ((u64)(s + LZ_PAD2) >> 2)); raw.qv = lz_load16(P.q2 + ((u64)(sq + LZ_PAD2) >> 2)); }
+    else       { raw.tv = lz_load16(P.t2 + ((u64)(s - 1 + LZ_PAD2) >> 2) - 15); raw.qv = lz_load16(P.q2 + ((u64)(sq - 1 + LZ_PAD2) >> 2) - 15); }
+    if constexpr (SPECIAL) {
+        if (RIGHT) { raw.tm = lz_load16(P.tsp + ((u64)(s + LZ_PAD2) >> 3)); raw.qm = lz_load16(P.qsp + ((u64)(sq + LZ_PAD2) >> 3)); }
+        else       { raw.tm = lz_load16(P.tsp + ((u64)(s - 1 + LZ_PAD2) >> 3) - 14); raw.qm = lz_load16(P.qsp + ((u64)(sq - 1 + LZ_PAD2) >> 3) - 14); }
+    }
 }
-
-// 128-bit window >> sh (sh < 32)
-LZ_HD void lz_lut_funnel(const LzVec16& v, u32 sh, u32 w[4])
-{
-    w[0] = lz_alignbit(v.w[1], v.w[0], sh); w[1] = lz_alignbit(v.w[2], v.w[1], sh);
-    w[2] = lz_alignbit(v.w[3], v.w[2], sh); w[3] = v.w[3] >> sh;
-}
-
-// how many bases from position s onwards (RIGHT) / from s-1 downwards (!RIGHT) are plain in this sequence: 0..64
+// 64 mask bits of one sequence from the 16 bytes lz_lut_fetch loaded: RIGHT: bit j = base s+j; LEFT: bit 63-j = base s-1-j
 template <bool RIGHT>
-LZ_HD u64 lz_lut_mask64(const u8* sp, s64 s)
+LZ_HD u64 lz_lut_mask64(const LzVec16& v, s64 s)
 {
     if (RIGHT) {
-        const u64 b = (u64)(s + LZ_PAD2);
-        const LzVec16 v = lz_load16(sp + (b >> 3));
-        const u32 k = (u32)(b & 7u);
-        const u32 lo = lz_alignbit(v.w[1], v.w[0], k), hi = lz_alignbit(v.w[2], v.w[1], k);
-        return ((u64)hi << 32) | lo;                    // bit j = base s + j
+        const u32 k = (u32)((u64)(s + LZ_PAD2) & 7u);
+        return ((u64)lz_alignbit(v.w[2], v.w[1], k) << 32) | lz_alignbit(v.w[1], v.w[0], k);
     }
-    const u64 b = (u64)(s - 1 + LZ_PAD2);
-    const LzVec16 v = lz_load16(sp + (b >> 3) - 14);   // base s-1 is bit 112 + (b & 7) of the 128 loaded bits
-    const u32 k = 17u + (u32)(b & 7u);                 // 17..24: bit 112+k' of v = bit 80+k' of (v >> 32) -> bit 63
-    const u32 lo = lz_alignbit(v.w[2], v.w[1], k), hi = lz_alignbit(v.w[3], v.w[2], k);
-    return ((u64)hi << 32) | lo;                        // bit 63 - j = base s - 1 - j
+    const u32 k = 17u + (u32)((u64)(s - 1 + LZ_PAD2) & 7u);     // base s-1 is bit 112 + k' of the loaded bits = bit 80 + k' of (v >> 32) -> bit 63
+    return ((u64)lz_alignbit(v.w[3], v.w[2], k) << 32) | lz_alignbit(v.w[2], v.w[1], k);
 }
 
-#define LZ_LUT_STEP(K, IDX, E)                                                                        \
-    if (go) {                                                                                        \
-        if (3u * ((K) + 1u) > lim) { go = false; gx = (K); ix = (IDX); }                             \
-        else if ((u32)m < ((E).ab & 0xFFFFu)) { go = false; fail = true; gx = (K); ix = (IDX); }     \
-        else { const s32 b_ = (s32)(E).ab >> 16; m = (m < b_ ? m : b_) + (E).c; run += (E).c; }    \
-    }
-
-// One 16-byte window (up to 60 bases) of one scan.  lut = this direction's table, m16 = the 4 x 4 matrix.
+// One 16-byte window (up to 60 bases = 15 groups) of one scan.  lut = this direction's table.
+// LIMCHK == false: the caller guarantees 60 plain bases (st.room >= 60, no special byte in reach): the limit tests
+// drop out of the straight-line part and the stopping group needs no general walk.
 // On return st.alive says whether the scan goes on into the next window.
-template <bool RIGHT, bool SPECIAL>
-LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, const s32* m16, s32 diag, LzLutScan& st)
+template <bool RIGHT, bool SPECIAL, bool LIMCHK>
+LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& st, const LzLutRaw<SPECIAL>& raw)
 {
     const s32 X = P.xdrop;
     const s64 s = (s64)st.s, sq = s - (s64)diag;
     u32 tw[4], qw[4];
-    if (RIGHT) {
-        const u64 bt = (u64)(s + LZ_PAD2), bq = (u64)(sq + LZ_PAD2);
-        const LzVec16 tv = lz_load16(P.t2 + (bt >> 2)), qv = lz_load16(P.q2 + (bq >> 2));
-        lz_lut_funnel(tv, 2u * (u32)(bt & 3u), tw);    // base s at bit 0
-        lz_lut_funnel(qv, 2u * (u32)(bq & 3u), qw);
-    } else {
-        const u64 bt = (u64)(s - 1 + LZ_PAD2), bq = (u64)(sq - 1 + LZ_PAD2);
-        const LzVec16 tv = lz_load16(P.t2 + (bt >> 2) - 15), qv = lz_load16(P.q2 + (bq >> 2) - 15);
-        lz_lut_funnel(tv, 2u * (u32)(bt & 3u), tw);    // base s-1 at bits 120-121
-        lz_lut_funnel(qv, 2u * (u32)(bq & 3u), qw);
+    {
+        const u32 a = RIGHT ? 2u * (u32)((u64)(s + LZ_PAD2) & 3u) : 2u * (u32)((u64)(s - 1 + LZ_PAD2) & 3u) + 2u;
+        const u32 b = RIGHT ? 2u * (u32)((u64)(sq + LZ_PAD2) & 3u) : 2u * (u32)((u64)(sq - 1 + LZ_PAD2) & 3u) + 2u;
+        tw[0] = lz_alignbit(raw.tv.w[1], raw.tv.w[0], a); tw[1] = lz_alignbit(raw.tv.w[2], raw.tv.w[1], a); tw[2] = lz_alignbit(raw.tv.w[3], raw.tv.w[2], a); tw[3] = raw.tv.w[3] >> a;
+        qw[0] = lz_alignbit(raw.qv.w[1], raw.qv.w[0], b); qw[1] = lz_alignbit(raw.qv.w[2], raw.qv.w[1], b); qw[2] = lz_alignbit(raw.qv.w[3], raw.qv.w[2], b); qw[3] = raw.qv.w[3] >> b;
     }
     u32 lim = st.room < (u32)LZ_LUT_WIN_B ? st.room : (u32)LZ_LUT_WIN_B;
     bool soft = false;
-    if (SPECIAL) {
-        const u64 sm = lz_lut_mask64<RIGHT>(P.tsp, s) | lz_lut_mask64<RIGHT>(P.qsp, sq);
+    if constexpr (SPECIAL) {
+        const u64 sm = lz_lut_mask64<RIGHT>(raw.tm, s) | lz_lut_mask64<RIGHT>(raw.qm, sq);
         const u32 nsp = sm ? (RIGHT ? lz_ctz64(sm) : lz_clz64(sm)) : 64u;
         if (nsp < lim) { soft = true; lim = nsp; }
     }
-    s32 run = st.run, m = run - st.best + X;
-    bool go = true, fail = false;
-    u32 gx = LZ_LUT_WIN_G, ix = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int blk = 0; blk < LZ_LUT_WIN_G / 4; blk++) {
-        if (LZ_WAVE_NONE(go)) break;
-        if (go) {
-            u32 idx[4]; LzLutEntry e[4];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < 4; k++) {
-                const int g = 4 * blk + k;
-                const int bit = RIGHT ? 6 * g : 116 - 6 * g;
-                idx[k] = (lz_lut_field(tw, bit) << 6) | lz_lut_field(qw, bit);
-                e[k] = lut[idx[k]];
-            }
-            LZ_LUT_STEP(4u * blk + 0u, idx[0], e[0])
-            LZ_LUT_STEP(4u * blk + 1u, idx[1], e[1])
-            LZ_LUT_STEP(4u * blk + 2u, idx[2], e[2])
-            LZ_LUT_STEP(4u * blk + 3u, idx[3], e[3])
-        }
+    // index planes: x = t ^ q (one byte per group), wc = the low bits of t's codes, four per byte in its low nibble
+    u32 xw[4], wc[4];
+    LZ_UNROLL_ALL
+    for (int k = 0; k < 4; k++) {
+        xw[k] = tw[k] ^ qw[k];
+        const u32 p = tw[k] & 0x55555555u;
+        const u32 u = (p | (p >> 1)) & 0x33333333u;
+        wc[k] = (u | (u >> 2)) & 0x0F0F0F0Fu;
     }
-    // the group the fast loop stopped in, base by base (the reference's loop)
+    // ---- the straight-line part: every group whose four bases lie inside the limit, until the margin test fails
+    const u32 glim = lim >> 2;
+    s32 run = st.run, m = run - st.best + X;
+    bool dead = false;
+    u32 nd = 0;                                                 // groups NOT passed (dead is sticky)
+    LZ_UNROLL_ALL
+    for (int g = 0; g < LZ_LUT_WIN_G; g++) {
+        const int byte = RIGHT ? g : 14 - g;
+        const LzLutEntry e = lut[lz_byte_pair(wc[byte >> 2], xw[byte >> 2], byte & 3)];
+        dead = dead | (m < (s32)(e.ab & 0xFFFFu));
+        if (LIMCHK) dead = dead | ((u32)g >= glim);
+        const s32 bq = (s32)e.ab >> 16;
+        const s32 t = lz_sdot4(e.sc, m < bq ? m : bq);
+        const s32 r2 = lz_sdot4(e.sc, run);
+        m = dead ? m : t; run = dead ? run : r2; nd += dead ? 1u : 0u;
+    }
+    const u32 np = (u32)LZ_LUT_WIN_G - nd;
+    // ---- the group the straight-line part stopped in (np < 15), base by base: the reference's loop
     u32 r = 0;
-    if (gx < (u32)LZ_LUT_WIN_G) r = fail ? 3u : lim - 3u * gx;         // (lim - 3 gx is 0..2 when the limit cut the group)
+    if (np < (u32)LZ_LUT_WIN_G) { r = lim - 4u * np; if (r > 4u) r = 4u; }       // 4: the margin test failed inside the limit
     s32 best = run - m + X;
-    bool dead = false; u32 j = 0;
-    const u32 tf = ix >> 6, qf = ix & 63u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (u32 b = 0; b < 3; b++) {
-        if (!dead && b < r) {
-            const u32 sh = RIGHT ? 2u * b : 2u * (2u - b);
-            run += m16[(((tf >> sh) & 3u) << 2) | ((qf >> sh) & 3u)];
-            j++;
-            if (run > best) best = run;
-            if (run < best - X) dead = true;
+    const u32 byte = (RIGHT ? np : 14u - np) & 15u, wsel = byte >> 2, bsh = 8u * (byte & 3u);
+    const u32 xsel = wsel == 0 ? xw[0] : wsel == 1 ? xw[1] : wsel == 2 ? xw[2] : xw[3];
+    const u32 csel = wsel == 0 ? wc[0] : wsel == 1 ? wc[1] : wsel == 2 ? wc[2] : wc[3];
+    const u32 sc = lut[(((csel >> bsh) & 0xFFu) << 8) | ((xsel >> bsh) & 0xFFu)].sc;
+    bool stop = false; u32 j = 0;
+    if (LIMCHK) {
+        LZ_UNROLL_ALL
+        for (u32 b = 0; b < 4; b++) {
+            const bool on = !stop && b < r;
+            const s32 nr = run + (s32)(int8_t)(sc >> (8u * b));
+            run = on ? nr : run;
+            j += on ? 1u : 0u;
+            best = (on && nr > best) ? nr : best;
+            stop = stop | (on && nr < best - X);
         }
+    } else if (r) {
+        // the margin test failed in this group: the scan stops on its first base that takes the margin below zero,
+        // and its best does not move (a group cannot gain and then lose more than xDrop)
+        const s32 p1 = m + (s32)(int8_t)sc, p2 = p1 + (s32)(int8_t)(sc >> 8), p3 = p2 + (s32)(int8_t)(sc >> 16), p4 = p3 + (s32)(int8_t)(sc >> 24);
+        const bool a1 = p1 >= 0, a2 = a1 && p2 >= 0, a3 = a2 && p3 >= 0;
+        j = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
+        stop = !(a3 && p4 >= 0);
+        const s32 q1 = (s32)(int8_t)sc, q2 = q1 + (s32)(int8_t)(sc >> 8), q3 = q2 + (s32)(int8_t)(sc >> 16);
+        run += j == 1 ? q1 : j == 2 ? q2 : j == 3 ? q3 : q3 + (s32)(int8_t)(sc >> 24);
     }
     st.run = run; st.best = best;
-    st.used += 3u * gx + j;
+    st.used += 4u * np + j;
     st.nwin++;
-    if (dead) st.alive = 0;
-    else if (fail) st.alive = 2;                                        // cannot happen with an eligible table; 2 = "undecided", the hit becomes SLOW
+    if (stop) st.alive = 0;
+    else if (r == 4u) st.alive = 2;                                     // cannot happen with an eligible table: "undecided", the hit becomes SLOW
     else if (soft) { st.used += 1u; st.alive = 0; }                     // the special base is consumed and ends the scan
     else if (lim == st.room) st.alive = 0;                              // end of a sequence / the left stop
     else { st.alive = 1; st.room -= (u32)LZ_LUT_WIN_B; st.s = RIGHT ? st.s + (u32)LZ_LUT_WIN_B : st.s - (u32)LZ_LUT_WIN_B; }
+}
+// fetch + window
+template <bool RIGHT, bool SPECIAL>
+LZ_HD void lz_lut_step(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& st)
+{
+    LzLutRaw<SPECIAL> raw;
+    lz_lut_fetch<RIGHT, SPECIAL>(P, st.s, diag, raw);
+    if (!SPECIAL && st.room >= (u32)LZ_LUT_WIN_B) lz_lut_window<RIGHT, SPECIAL, false>(P, lut, diag, st, raw);
+    else                                           lz_lut_window<RIGHT, SPECIAL, true>(P, lut, diag, st, raw);
 }
 
 // scan set-up of one raw hit (diagEnd == 0, as in lz_probe_head)
@@ -194,20 +210,21 @@ LZ_HD u32 lz_lut_summary(const LzLutScan& L, const LzLutScan& R, s32 min_score)
 }
 
 template <bool SPECIAL>
-LZ_HD u32 lz_lut_probe_hit(const LzLutParams& P, const LzLutEntry* lut_r, const LzLutEntry* lut_l, const s32* m16,
+LZ_HD u32 lz_lut_probe_hit(const LzLutParams& P, const LzLutEntry* lut_r, const LzLutEntry* lut_l,
                            u32 tlen, u32 qlen, s32 min_score, u64 key)
 {
     s32 diag; LzLutScan L, R;
     lz_lut_init(key, tlen, qlen, diag, L, R);
-    while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<false, SPECIAL>(P, lut_l, m16, diag, L);
-    while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<true, SPECIAL>(P, lut_r, m16, diag, R);
+    while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SPECIAL>(P, lut_l, diag, L);
+    while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SPECIAL>(P, lut_r, diag, R);
     return lz_lut_summary(L, R, min_score);
 }
 
 // ---- the hit record that travels from phase A to phase B (one u64 per raw hit, partitioned by the high
 // 8 bits of hashedDiag, in discovery order inside a partition):
 //   bits  0..30  pos2 (end of the seed word in the query)
-//   bits 31..38  low 8 bits of hashedDiag (the bucket inside its partition)
+//   bits 31..38  low 8 bits of hashedDiag (the bucket inside its partition); phase B overwrites them (and bits
+//                55..59) with the record's index inside its tile once the record sits in its bucket's list
 //   bits 39..54  fast hits: bases the left scan consumed | bases the right scan consumed << 8
 //                SLOW hits: bits 16..31 of the diagonal pos1 - pos2 (the low 16 are the bucket)
 //   bit  63      SLOW
@@ -222,6 +239,10 @@ LZ_HD u64 lz_hit_record(u64 key, u32 summ)
 #define LZ_REC_LOW8(r)    ((u32)((r) >> 31) & 0xFFu)
 #define LZ_REC_PAYLOAD(r) ((u32)((r) >> 39) & 0xFFFFu)
 #define LZ_REC_SLOW(r)    ((u32)((r) >> 63))
+// the tile index phase B stores in a placed record (13 bits: low 8 in the bucket field, high 5 in bits 55..59)
+LZ_HD u64 lz_rec_with_index(u64 r, u32 idx)
+{ return (r & ~((0xFFull << 31) | (0x1Full << 55))) | ((u64)(idx & 0xFFu) << 31) | ((u64)((idx >> 8) & 0x1Fu) << 55); }
+#define LZ_REC_INDEX(r)   (((u32)((r) >> 31) & 0xFFu) | (((u32)((r) >> 55) & 0x1Fu) << 8))
 
 // ---- phase B: one record of a bucket's stream, in discovery order, with diagEnd[h] in `dend`.
 // This is process_for_simple_hit + xdrop_extend_seed_hit (src/seed_search.c:1056-1192, 2528-2959) for hit
@@ -244,6 +265,9 @@ LZ_HD void lz_settle_record(const LzExtendParams& P, const s32* score_tab, u64 r
         if (extent > dend) dend = extent;
         return;
     }
+#if defined(LZ_EXPERIMENT_NOSLOW)                               // timing experiment only (results are wrong): what phase B costs without re-extensions
+    dend = p2 + 100; return;
+#endif
     const s32 diag = (s32)((pay << 16) | h);
     dend = lz_reextend(P, score_tab, p2, diag, dend, n_bp, emit);
 }

@@ -18,6 +18,7 @@
 
 static LzCtx g_ctx;
 static void lz_release_statics();
+void lz_phase_clocks_print();                                 // seed_kernels.hip (prints only in a -DLZ_PHASE_CLOCKS build)
 LzCtx& lz_ctx() { return g_ctx; }
 
 int lz_fail(int code, const char* fmt, ...)
@@ -146,10 +147,11 @@ extern "C" void lzgpu_shutdown(void)
     LzCtx& c = g_ctx;
     if (!c.inited) return;
     (void)hipStreamSynchronize(c.stream);
+    lz_phase_clocks_print();
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     c.timer.resolve();
     if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.recs[0], &c.recs[1], &c.bin_base[0], &c.bin_base[1], &c.hist, &c.hist_part, &c.lut, &c.m16,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.recs[0], &c.recs[1], &c.bin_base[0], &c.bin_base[1], &c.hist, &c.hist_part, &c.lut,
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
@@ -546,10 +548,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
                 lut_host.resize(2 * LZ_LUT_ENTRIES);
                 lzh_lut_build(M4, a->xdrop, lut_host.data());
                 if ((rc = c.lut.ensure(lut_host.size() * sizeof(LzLutEntry)))) return rc;
-                if ((rc = c.m16.ensure(sizeof(M4)))) return rc;
                 memcpy(lut_m4, M4, sizeof(M4)); lut_x = a->xdrop;
                 LZ_HIP(hipMemcpyAsync(c.lut.p, lut_host.data(), lut_host.size() * sizeof(LzLutEntry), hipMemcpyHostToDevice, c.stream));
-                LZ_HIP(hipMemcpyAsync(c.m16.p, lut_m4, sizeof(M4), hipMemcpyHostToDevice, c.stream));
                 LZ_HIP(hipStreamSynchronize(c.stream));
             }
         }
@@ -580,7 +580,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         const int set = (int)(ci & 1) % nsets;
         if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
         if ((rc = lzk_hist(c, c.keys_a.as<u64>(), ch.nh, c.hist.as<u32>(), c.hist_part.as<u32>(), c.bin_base[set].as<u32>()))) return rc;
-        if ((rc = lzk_probe_part(c, mode, P, Q, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(), c.m16.as<s32>(),
+        if ((rc = lzk_probe_part(c, mode, P, Q, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(),
                                  c.hist.as<u32>(), c.hist_part.as<u32>(), c.recs[set].as<u64>()))) return rc;
         LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
         LZ_HIP(hipStreamWaitEvent(sB, c.ev_sorted[set], 0));

@@ -11,11 +11,13 @@
 // every bucket walked by one lane with diagEnd[h] in a register (phase B, k_settle).
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdio>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include "lz_ctx.hpp"
 #include "lz_lut.hpp"
+#include "lz_coop.hpp"
 
 #define LZ_TPB 256
 
@@ -399,7 +401,7 @@ k_pack2(const u8* __restrict__ code /*base 0*/, u32 len, u8* __restrict__ two, u
     for (int k = 0; k < 8; k++) {
         const s64 i = b0 + k;
         const u32 c = (i >= -(s64)LZ_SEQ_PAD && i < (s64)len + LZ_SEQ_PAD) ? code[i] : (u32)LZ_CODE_INVALID;
-        if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_CODE_BITS(c) << (2 * k);
+        if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_GRAY(LZ_CODE_BITS(c)) << (2 * k);
     }
     spc[j] = (u8)m;
     two[2 * (size_t)j] = (u8)bits; two[2 * (size_t)j + 1] = (u8)(bits >> 8);
@@ -447,11 +449,32 @@ int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* tw
 // 8-byte records (lz_lut.hpp), one stream per workgroup of phase B.  One pass over the keys for the partition
 // offsets (k_hist + two small scans), one pass that scans and scatters (k_probe_part): 8 B read + 8 B read +
 // 8 B written per hit, where a radix sort of (key, summary) pairs moved 56.
+// -DLZ_PHASE_CLOCKS: per-phase shader-clock totals of k_probe_part / k_settle (lane 0 of every workgroup adds
+// its s_memtime deltas to a device array the host prints at shutdown); off in the product build
+#if defined(LZ_PHASE_CLOCKS)
+__device__ unsigned long long g_phase_clk[32];
+#define LZ_CLK_DECL  unsigned long long _t0 = __builtin_readcyclecounter(), _t1
+#define LZ_CLK(slot) do { if (threadIdx.x == 0) { _t1 = __builtin_readcyclecounter(); atomicAdd(&g_phase_clk[slot], _t1 - _t0); _t0 = _t1; } } while (0)
+void lz_phase_clocks_print()
+{
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof(h)) != hipSuccess) return;
+    fprintf(stderr, "[lzgpu phase clocks] probe_part:");
+    for (int k = 0; k < 10; k++) fprintf(stderr, " %llu", h[k]);
+    fprintf(stderr, "\n[lzgpu phase clocks] settle:");
+    for (int k = 16; k < 26; k++) fprintf(stderr, " %llu", h[k]);
+    fprintf(stderr, "\n");
+}
+#else
+#define LZ_CLK_DECL
+#define LZ_CLK(slot)
+void lz_phase_clocks_print() {}
+#endif
 #define LZ_PP_TPB    1024
 #define LZ_PP_WAVES  (LZ_PP_TPB / 64)
 #define LZ_PP_ROUNDS 4
 #define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile
-#define LZ_PP_QCAP   1024                            // unfinished scans a tile can queue (more are continued in place)
+#define LZ_PP_QCAP   256                             // unfinished scans a tile can queue (beyond that the hit is left to phase B)
 #define LZ_NBIN      256
 #define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // bits 8..15 of hashedDiag
 
@@ -540,224 +563,430 @@ __device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
     return pre + inc - v;
 }
 
-struct LzPPTask { u32 s; s32 run, best; u32 room, used, nwin; s32 diag; u32 side; };
+// One workgroup of 1024 lanes per tile of 4096 hits (a wave owns 256 consecutive hits, 64 at a time); the
+// kernel is a sequence of short rolled loops over those four rounds, what a hit needs from one loop to the next
+// travels through LDS (info[]), so that the heavy code -- the unrolled, branch-free window of lz_lut.hpp --
+// exists four times only (head and continuation, left and right) and the register budget stays at 4 waves / SIMD.
+struct LzPPTask { u32 s; s32 run, best; u32 room, used, nwin; s32 diag; u32 li_side; };
+#define LZ_PP_INFO(used, alive, best) (((used) & 0xFFu) | (((alive) & 3u) << 8) | ((u32)(best) << 16))
 struct LzPPShared {
-    LzLutEntry lut[2 * LZ_LUT_ENTRIES];              // MODE 0/1: right table, left table (64 KiB)
-    s32 m16[16];
-    s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64];    // MODE 2: the byte-code scans' tables
+    union {
+        LzLutEntry lut[2 * LZ_LUT_ENTRIES];                             // MODE 0/1: right table, left table (64 KiB)
+        struct { s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64]; } bc;    // MODE 2: the byte-code scans' tables
+    };
+    u32 info[2 * LZ_PP_TILE];                        // per hit: left / right scan: bases consumed | alive << 8 | best << 16 (MODE 2: the summary)
     u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition
     u8  sbin[LZ_PP_TILE];
-    unsigned short wcnt[LZ_PP_WAVES][LZ_NBIN];       // per wave and partition: records so far / start inside the partition
+    u32 wcnt[LZ_PP_WAVES][LZ_NBIN];                  // per wave and partition: records / running offset inside the partition
     u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
     LzPPTask q[LZ_PP_QCAP]; u32 qn;
 };
+static_assert(LZ_PP_TILE == 4096 && sizeof(LzPPShared) <= 160 * 1024, "LDS budget of k_probe_part");
 
 template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
 __global__ void __launch_bounds__(LZ_PP_TPB)
 k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n, u32 ntiles,
-             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g, const s32* __restrict__ m16_g,
+             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
              const u32* __restrict__ hist, const u32* __restrict__ part, u64* __restrict__ recs)
 {
     __shared__ LzPPShared sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (MODE < 2) {
-        for (u32 k = tid; k < 2 * LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k];
-        if (tid < 16) sh.m16[tid] = m16_g[tid];
-    } else {
-        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PP_TPB) sh.tab[k] = score_tab_g[k];
-        if (tid < 64) sh.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
+    if (MODE < 2) { for (u32 k = tid; k < 2 * LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k]; }
+    else {
+        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PP_TPB) sh.bc.tab[k] = score_tab_g[k];
+        if (tid < 64) sh.bc.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
     }
     const LzLutEntry* lut_r = sh.lut; const LzLutEntry* lut_l = sh.lut + LZ_LUT_ENTRIES;
     constexpr bool SP = MODE == 1;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const u64 base = (u64)tile * LZ_PP_TILE;
         const u32 tile_n = (n - base < (u64)LZ_PP_TILE) ? (u32)(n - base) : (u32)LZ_PP_TILE;
+        LZ_CLK_DECL;
         if (tid == 0) sh.qn = 0;
-        for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN / 2; k += LZ_PP_TPB) reinterpret_cast<u32*>(&sh.wcnt[0][0])[k] = 0;
+        for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN; k += LZ_PP_TPB) (&sh.wcnt[0][0])[k] = 0;
         __syncthreads();
+        LZ_CLK(0);
 
-        // ---- phase A heads: one window per side for every hit; unfinished scans are queued
-        u64 key[LZ_PP_ROUNDS]; u32 summ[LZ_PP_ROUNDS];
-        u32 usedl[LZ_PP_ROUNDS], usedr[LZ_PP_ROUNDS]; s32 bestl[LZ_PP_ROUNDS], bestr[LZ_PP_ROUNDS];
-        int slotl[LZ_PP_ROUNDS], slotr[LZ_PP_ROUNDS]; u32 alive[LZ_PP_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
-            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
-            const bool valid = li < tile_n;
-            key[r] = valid ? keys[base + li] : 0ull;
-            summ[r] = 0; usedl[r] = usedr[r] = 0; bestl[r] = bestr[r] = 0; slotl[r] = slotr[r] = -1; alive[r] = 0;
-            if (MODE == 2) { if (valid) summ[r] = lz_probe_hit(P, sh.tab, sh.tab8, P.cls8 != 0, key[r]); continue; }
-            s32 diag; LzLutScan L, R;
-            lz_lut_init(key[r], P.tlen, P.qlen, diag, L, R);
-            if (!valid) { L.alive = 0; R.alive = 0; }
-            if (L.alive) lz_lut_window<false, SP>(Q, lut_l, sh.m16, diag, L);
-            if (R.alive) lz_lut_window<true, SP>(Q, lut_r, sh.m16, diag, R);
-            if (L.alive == 1) {
-                const u32 slot = atomicAdd(&sh.qn, 1u);
-                if (slot < LZ_PP_QCAP) { sh.q[slot] = { L.s, L.run, L.best, L.room, L.used, L.nwin, diag, 0u }; slotl[r] = (int)slot; }
-                else while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<false, SP>(Q, lut_l, sh.m16, diag, L);
-            }
-            if (R.alive == 1) {
-                const u32 slot = atomicAdd(&sh.qn, 1u);
-                if (slot < LZ_PP_QCAP) { sh.q[slot] = { R.s, R.run, R.best, R.room, R.used, R.nwin, diag, 1u }; slotr[r] = (int)slot; }
-                else while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<true, SP>(Q, lut_r, sh.m16, diag, R);
-            }
-            usedl[r] = L.used; usedr[r] = R.used; bestl[r] = L.best; bestr[r] = R.best;
-            alive[r] = (L.alive ? 1u : 0u) | (R.alive ? 2u : 0u);
+        // ---- phase A, first window of both scans of every hit; a scan that goes on is queued.  The four keys of a
+        // lane are requested together and the windows of round r + 1 before round r is computed, so that the
+        // wave has its next loads in flight while it works.
+        constexpr bool HLIM = SP;                    // MODE 0 heads run without limit tests: a side with less than 60 bases of room is queued
+        u64 k0, k1, k2, k3;
+        {
+            const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
+            k0 = (l0 < tile_n) ? keys[base + l0] : 0ull;             k1 = (l0 + 64u < tile_n) ? keys[base + l0 + 64u] : 0ull;
+            k2 = (l0 + 128u < tile_n) ? keys[base + l0 + 128u] : 0ull; k3 = (l0 + 192u < tile_n) ? keys[base + l0 + 192u] : 0ull;
         }
+        if (MODE == 2) {
+#pragma unroll 1
+            for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+                const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
+                const bool valid = li < tile_n;
+                sh.info[2 * li] = valid ? lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, k0) : 0u;
+                if (valid) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(k0)], 1u);
+                const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
+            }
+        } else {
+            s32 diag; LzLutScan L, R; LzLutRaw<SP> rawl, rawr;
+            lz_lut_init(k0, P.tlen, P.qlen, diag, L, R);
+            lz_lut_fetch<false, SP>(Q, L.s, diag, rawl); lz_lut_fetch<true, SP>(Q, R.s, diag, rawr);
+#pragma unroll 1
+            for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+                const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
+                const bool valid = li < tile_n;
+                // the next round's windows
+                s32 ndiag; LzLutScan NL, NR; LzLutRaw<SP> nrawl, nrawr;
+                lz_lut_init(k1, P.tlen, P.qlen, ndiag, NL, NR);
+                if (r + 1 < LZ_PP_ROUNDS) { lz_lut_fetch<false, SP>(Q, NL.s, ndiag, nrawl); lz_lut_fetch<true, SP>(Q, NR.s, ndiag, nrawr); }
+                else { nrawl = rawl; nrawr = rawr; }
+                if (!valid) { L.alive = 0; R.alive = 0; }
+                const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
+                if (L.alive && !ql) lz_lut_window<false, SP, HLIM>(Q, lut_l, diag, L, rawl);
+                if (R.alive && !qr) lz_lut_window<true, SP, HLIM>(Q, lut_r, diag, R, rawr);
+                if (L.alive == 1) {
+                    const u32 slot = atomicAdd(&sh.qn, 1u);          // (a full queue leaves the scan "alive": the hit becomes SLOW)
+                    if (slot < LZ_PP_QCAP) sh.q[slot] = { L.s, L.run, L.best, L.room, L.used, L.nwin, diag, (li << 1) | 0u };
+                }
+                if (R.alive == 1) {
+                    const u32 slot = atomicAdd(&sh.qn, 1u);
+                    if (slot < LZ_PP_QCAP) sh.q[slot] = { R.s, R.run, R.best, R.room, R.used, R.nwin, diag, (li << 1) | 1u };
+                }
+                sh.info[2 * li] = LZ_PP_INFO(L.used, L.alive, L.best);
+                sh.info[2 * li + 1] = LZ_PP_INFO(R.used, R.alive, R.best);
+                if (valid) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(k0)], 1u);         // the partition counts, per (wave, partition)
+                const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
+                diag = ndiag; L = NL; R = NR; rawl = nrawl; rawr = nrawr;
+            }
+        }
+        LZ_CLK(1);
+        __syncthreads();
+        LZ_CLK(2);
         if (MODE < 2) {
-            __syncthreads();
-            // ---- the queued scans, one lane per scan, to the end (or the cap)
+            // ---- the queued scans, one lane per scan, to their end (or the cap of LZ_LUT_MAXWIN windows)
             const u32 nq = sh.qn < (u32)LZ_PP_QCAP ? sh.qn : (u32)LZ_PP_QCAP;
             for (u32 k = tid; k < nq; k += LZ_PP_TPB) {
                 const LzPPTask t = sh.q[k];
                 LzLutScan S; S.s = t.s; S.run = t.run; S.best = t.best; S.room = t.room; S.used = t.used; S.nwin = t.nwin; S.alive = 1;
-                if (t.side) while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<true, SP>(Q, lut_r, sh.m16, t.diag, S);
-                else        while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_window<false, SP>(Q, lut_l, sh.m16, t.diag, S);
-                sh.q[k].used = S.used; sh.q[k].best = S.best; sh.q[k].side = S.alive;     // results travel back through the slot
+                while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) {
+                    LzLutRaw<SP> raw;
+                    if (t.li_side & 1u) { lz_lut_fetch<true, SP>(Q, S.s, t.diag, raw);  lz_lut_window<true, SP, true>(Q, lut_r, t.diag, S, raw); }
+                    else                { lz_lut_fetch<false, SP>(Q, S.s, t.diag, raw); lz_lut_window<false, SP, true>(Q, lut_l, t.diag, S, raw); }
+                }
+                sh.info[t.li_side] = LZ_PP_INFO(S.used, S.alive, S.best);
             }
+            LZ_CLK(3);
             __syncthreads();
-#pragma unroll
-            for (int r = 0; r < LZ_PP_ROUNDS; r++) {
-                if (slotl[r] >= 0) { const LzPPTask& t = sh.q[slotl[r]]; usedl[r] = t.used; bestl[r] = t.best; alive[r] = (alive[r] & ~1u) | (t.side ? 1u : 0u); }
-                if (slotr[r] >= 0) { const LzPPTask& t = sh.q[slotr[r]]; usedr[r] = t.used; bestr[r] = t.best; alive[r] = (alive[r] & ~2u) | (t.side ? 2u : 0u); }
-                u32 s = (usedl[r] & 0xFFu) | ((usedr[r] & 0xFFu) << 8);
-                if (alive[r] || bestl[r] + bestr[r] >= P.min_score) s |= LZ_SUMM_SLOW;
-                summ[r] = s;
-            }
+            LZ_CLK(4);
         }
-
-        // ---- stable partition of the tile's records: rank inside (wave, partition), then the waves' counts are
-        // chained in wave order (= discovery order: a wave holds 256 consecutive hits)
-        u32 lrank[LZ_PP_ROUNDS], bin[LZ_PP_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
-            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
-            const bool valid = li < tile_n;
-            bin[r] = LZ_KEY_BIN(key[r]);
-            u32 rank, count; bool last;
-            lz_match8(bin[r], valid, lane, rank, count, last);
-            const u32 old = sh.wcnt[w][bin[r]];
-            if (valid && last) sh.wcnt[w][bin[r]] = (unsigned short)(old + count);
-            lrank[r] = old + rank;
-        }
-        __syncthreads();
+        LZ_CLK(5);
+        // ... chained in wave order (= discovery order: a wave holds 256 consecutive hits) ...
         u32 tot = 0;
         if (tid < LZ_NBIN) {
-            for (u32 k = 0; k < LZ_PP_WAVES; k++) { const u32 v = sh.wcnt[k][tid]; sh.wcnt[k][tid] = (unsigned short)tot; tot += v; }
+            for (u32 k = 0; k < LZ_PP_WAVES; k++) { const u32 v = sh.wcnt[k][tid]; sh.wcnt[k][tid] = tot; tot += v; }
             sh.gbase[tid] = part[(size_t)(tile >> 8) * LZ_NBIN + tid] + hist[(size_t)tile * LZ_NBIN + tid];
         }
         const u32 ts = lz_exscan256(tot, sh.wtot);
         if (tid < LZ_NBIN) sh.tstart[tid] = ts;
         if (tid == 0) sh.tstart[LZ_NBIN] = tile_n;
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < LZ_PP_ROUNDS; r++) {
-            const u32 li = w * (64u * LZ_PP_ROUNDS) + (u32)r * 64u + lane;
-            if (li < tile_n) {
-                const u32 pos = sh.tstart[bin[r]] + sh.wcnt[w][bin[r]] + lrank[r];
-                sh.stage[pos] = lz_hit_record(key[r], summ[r]);
-                sh.sbin[pos] = (u8)bin[r];
+        LZ_CLK(6);
+        // ... then every record gets its place: rank among the same-partition lanes of its wave's round, on top of
+        // the wave's running offset (stable: lanes, rounds and waves all follow the discovery order)
+        {
+            const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
+            k0 = (l0 < tile_n) ? keys[base + l0] : 0ull;             k1 = (l0 + 64u < tile_n) ? keys[base + l0 + 64u] : 0ull;
+            k2 = (l0 + 128u < tile_n) ? keys[base + l0 + 128u] : 0ull; k3 = (l0 + 192u < tile_n) ? keys[base + l0 + 192u] : 0ull;
+        }
+#pragma unroll 1
+        for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+            const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
+            const bool valid = li < tile_n;
+            const u64 key = k0;
+            { const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t; }
+            const u32 bin = LZ_KEY_BIN(key);
+            u32 rank, count; bool last;
+            lz_match8(bin, valid, lane, rank, count, last);
+            const u32 old = sh.wcnt[w][bin];
+            if (valid && last) sh.wcnt[w][bin] = old + count;
+            if (valid) {
+                u32 summ;
+                if (MODE == 2) summ = sh.info[2 * li];
+                else {
+                    const u32 il = sh.info[2 * li], ir = sh.info[2 * li + 1];
+                    summ = (il & 0xFFu) | ((ir & 0xFFu) << 8);
+                    if (((il | ir) & 0x300u) || (s32)((il >> 16) + (ir >> 16)) >= P.min_score) summ |= LZ_SUMM_SLOW;
+                }
+                const u32 pos = sh.tstart[bin] + old + rank;
+                sh.stage[pos] = lz_hit_record(key, summ);
+                sh.sbin[pos] = (u8)bin;
             }
         }
         __syncthreads();
+        LZ_CLK(7);
         for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
             const u32 b = sh.sbin[k];
             recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = sh.stage[k];
         }
         __syncthreads();
+        LZ_CLK(8);
     }
 }
 
 int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                   const s32* score_tab, const LzLutEntry* lut, const s32* m16, const u32* hist, const u32* part, u64* recs)
+                   const s32* score_tab, const LzLutEntry* lut, const u32* hist, const u32* part, u64* recs)
 {
     if (n == 0) return 0;
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE);
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
-    const u32 grid = ntiles < (u32)cus ? ntiles : (u32)cus;     // one 1024-thread workgroup per CU (the tables fill most of its LDS)
+    const u32 grid = ntiles < (u32)cus ? ntiles : (u32)cus;     // one 1024-lane workgroup per CU (the tables fill most of its LDS)
     c.timer.begin("k_probe_part", c.stream);
-    if (mode == 0)      hipLaunchKernelGGL(k_probe_part<0>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
-    else if (mode == 1) hipLaunchKernelGGL(k_probe_part<1>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
-    else                hipLaunchKernelGGL(k_probe_part<2>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, m16, hist, part, recs);
+    if (mode == 0)      hipLaunchKernelGGL(k_probe_part<0>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
+    else if (mode == 1) hipLaunchKernelGGL(k_probe_part<1>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
+    else                hipLaunchKernelGGL(k_probe_part<2>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------
-// B2 step 4 (phase B): one workgroup per partition (256 buckets), one lane per bucket with diagEnd[h] in a
-// register.  The partition's records arrive in discovery order; a tile of them is loaded with coalesced reads,
-// dealt out to the buckets inside LDS (counting sort by the record's low hash bits: counts, offsets, placement),
-// and every lane then walks its own short list in order (lz_settle_record).
-#define LZ_ST_TPB    256
-#define LZ_ST_TILE   2048
+// The X-drop extension of one hit by a whole wave (lz_coop.hpp): every argument is wave-uniform, all 64 lanes
+// take part -- lanes 0..31 run the left scan (loop 1), lanes 32..63 the right scan (loop 2), 16 bases per lane and
+// step.  tab = the 32 x 32 class table in LDS.  Every lane returns its own side's result.
+__device__ __forceinline__ LzCoopMap lz_coop_shfl_up32(const LzCoopMap& v, int d)
+{ LzCoopMap r; r.A = __shfl_up(v.A, d, 32); r.B = __shfl_up(v.B, d, 32); r.C = __shfl_up(v.C, d, 32); return r; }
+__device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* tab, u32 pos1, s32 diag, s32 stopl, s32 stopr, u32 lane)
+{
+    const s32 X = P.xdrop;
+    const bool right = lane >= 32u;
+    const u32 hl = lane & 31u;
+    const s32 stop = right ? stopr : stopl;
+    LzCoopSide out; out.stop_pos = pos1; out.best_pos = pos1; out.best = 0;
+    s32 run0 = 0, best0 = 0; u32 s = pos1;
+    bool alive = (right ? ((s32)s < stop) : ((s32)s > stop)) && X >= 0;        // uniform inside a half
+    while (__ballot(alive)) {
+        const u32 room = alive ? (right ? (u32)(stop - (s32)s) : (u32)((s32)s - stop)) : 0u;
+        const u32 off = LZ_COOP_BLK * hl;
+        const u32 nb = room > off ? (room - off < (u32)LZ_COOP_BLK ? room - off : (u32)LZ_COOP_BLK) : 0u;
+        s32 sc[LZ_COOP_BLK];
+        {
+            LzVec16 tv = { { 0, 0, 0, 0 } }, qv = { { 0, 0, 0, 0 } };
+            if (nb) {
+                const s64 t0 = right ? (s64)s + off : (s64)s - off - LZ_COOP_BLK;
+                tv = lz_load16(P.tcode + t0); qv = lz_load16(P.qcode + (t0 - diag));
+            }
+#pragma unroll
+            for (int j = 0; j < LZ_COOP_BLK; j++) {
+                const u32 tb = right ? LZ_VBYTE(tv, j) : LZ_VBYTE(tv, LZ_COOP_BLK - 1 - j);      // consumption order
+                const u32 qb = right ? LZ_VBYTE(qv, j) : LZ_VBYTE(qv, LZ_COOP_BLK - 1 - j);
+                sc[j] = tab[(LZ_CODE_CLASS(tb) << 5) | LZ_CODE_CLASS(qb)];
+            }
+        }
+        LzCoopMap f; s32 mx; u32 jmx;
+        lz_coop_block(sc, nb, X, f, mx, jmx);
+        // inclusive scan of the maps in lane order inside the half (lower lanes act first), then shifted by one lane
+        LzCoopMap inc = f;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const LzCoopMap g = lz_coop_shfl_up32(inc, d); if ((int)hl >= d) inc = lz_coop_compose(g, inc); }
+        LzCoopMap ex = lz_coop_shfl_up32(inc, 1);
+        if (hl == 0) ex = lz_coop_identity(X);
+        const s32 m0 = run0 - best0 + X;
+        const bool dead_before = lz_coop_fails(ex, m0);
+        const s32 mi = lz_coop_apply(ex, m0), ri = run0 + ex.C;
+        const bool fails_here = nb && !dead_before && lz_coop_fails(f, mi);
+        const u64 fboth = __ballot(fails_here);                 // at most one lane per half: the blocks after it are "dead before"
+        const u32 fmask = right ? (u32)(fboth >> 32) : (u32)fboth;
+        // best prefix: (value, first position) as one key, larger is better
+        long long key = -1;
+        u32 used_here = 0;
+        if (fails_here) {
+            u32 used; bool stopped; s32 rmx; u32 rj;
+            lz_coop_resolve(sc, nb, X, mi, ri, used, stopped, rmx, rj);
+            used_here = used;
+            if (rj) key = (((long long)rmx + LZ_COOP_INF) << 16) | (long long)(0xFFFFu - (off + rj));
+        } else if (nb && jmx && !dead_before)
+            key = (((long long)ri + mx + LZ_COOP_INF) << 16) | (long long)(0xFFFFu - (off + jmx));
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) { const long long o = __shfl_xor(key, d, 32); if (o > key) key = o; }
+        const int fl = fmask ? (int)__ffs((int)fmask) - 1 : 0;
+        const u32 used_f = (u32)__shfl((int)used_here, fl, 32);
+        const s32 totc = __shfl(inc.C, 31, 32);
+        if (alive) {
+            u32 used_total;
+            if (fmask) { used_total = LZ_COOP_BLK * (u32)fl + used_f; alive = false; }
+            else {
+                used_total = room < (u32)(LZ_COOP_BLK * LZ_COOP_LANES) ? room : (u32)(LZ_COOP_BLK * LZ_COOP_LANES);
+                if (room <= (u32)(LZ_COOP_BLK * LZ_COOP_LANES)) alive = false;
+            }
+            if (key >= 0) {
+                const s32 v = (s32)((key >> 16) - LZ_COOP_INF); const u32 idx = 0xFFFFu - (u32)(key & 0xFFFF);
+                if (v > best0) { best0 = v; out.best_pos = right ? s + idx : s - idx; }
+            }
+            run0 += totc;
+            s = right ? s + used_total : s - used_total;
+        }
+    }
+    out.stop_pos = s; out.best = best0;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// B2 step 4 (phase B): one workgroup of 1024 lanes per partition (256 buckets).  The partition's records arrive
+// in discovery order; a tile of 8192 of them is loaded with coalesced reads and dealt out to the buckets inside
+// LDS by all 16 waves (counting sort by the record's low hash bits: the counting atomic hands every record its
+// rank inside (wave, bucket), offsets, placement of the records themselves so that a bucket's list is contiguous),
+// then the first 256 lanes walk one bucket each with diagEnd[h] in a register (the fast path of
+// lz_settle_record): the serial part of the whole search is this short walk.  Records a wave counted in the
+// same step get their ranks from LDS atomics in no particular order: every placed record carries its index in the
+// tile and the walk checks that the indices ascend (discovery order), sorting the rest of its list when they do
+// not.  A record that needs a real extension (an HSP candidate that passed the diagEnd test) is extended by the
+// lane's whole wave (lz_coop_extend_wave), one such record at a time.
+#define LZ_ST_TPB    1024
+#define LZ_ST_WAVES  (LZ_ST_TPB / 64)
+#define LZ_ST_TILE   8192
 #define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
+#define LZ_ST_BATCH  4
 __global__ void __launch_bounds__(LZ_ST_TPB)
 k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__ bin_base, u32* __restrict__ diag_end,
          const s32* __restrict__ score_tab_g, LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap,
          u64* __restrict__ counters)
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
-    __shared__ u64 rec[LZ_ST_TILE];
-    __shared__ unsigned short list[LZ_ST_TILE];
-    __shared__ u32 cnt[4][LZ_NBIN];
+    __shared__ u64 rec[LZ_ST_TILE + LZ_ST_BATCH];
+    __shared__ u32 cnt[LZ_ST_WAVES][LZ_NBIN];
     __shared__ u32 wtot[4];
+    __shared__ u32 lbeg[LZ_NBIN], lcnt[LZ_NBIN];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     for (int k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_ST_TPB) tab[k] = score_tab_g[k];
-    const u32 h = blockIdx.x * LZ_NBIN + tid;
-    u32 dend = diag_end[h];
+    // The walk is bound by the latency of its short dependent steps, not by lanes: the 256 buckets are spread over
+    // all 16 waves (16 lanes each), so that every SIMD has four walking waves to interleave instead of one.
+    const bool walker = lane < (LZ_NBIN / LZ_ST_WAVES);
+    const u32 bucket = lane * LZ_ST_WAVES + w;                  // of a walker lane
+    const u32 h = blockIdx.x * LZ_NBIN + (bucket & (LZ_NBIN - 1));
+    const u32 L = P.seed_len;
+    u32 dend = walker ? diag_end[h] : 0u;
     u64 n_ext = 0, n_bp = 0;
     const u32 r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
-    auto emit = [&](const LzHspRec& r) { const u32 slot = atomicAdd(out_count, 1u); if (slot < out_cap) out[slot] = r; };
-    // a wave owns a quarter of the tile (consecutive records), which it takes 64 at a time
+    // a wave owns 512 consecutive records of the tile, which it takes 64 at a time
     u64 x[LZ_ST_ROUNDS];
 #pragma unroll
-    for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane; x[rr] = ((u64)r0 + li < (u64)r1) ? recs[(size_t)r0 + li] : 0ull; }
+    for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane; x[rr] = ((u64)r0 + li < (u64)r1) ? recs[(size_t)r0 + li] : 0ull; }
     for (u32 t0 = r0; t0 < r1; t0 += LZ_ST_TILE) {
         const u32 nt = (r1 - t0 < (u32)LZ_ST_TILE) ? r1 - t0 : (u32)LZ_ST_TILE;
-#pragma unroll
-        for (int k = 0; k < 4; k++) cnt[k][tid] = 0;
+        LZ_CLK_DECL;
+        for (u32 k = tid; k < LZ_ST_WAVES * LZ_NBIN; k += LZ_ST_TPB) (&cnt[0][0])[k] = 0;
         __syncthreads();
-        u32 slot[LZ_ST_ROUNDS], k8[LZ_ST_ROUNDS];
+        LZ_CLK(16);
+        u32 slot[LZ_ST_ROUNDS];
 #pragma unroll
         for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
-            const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane;
-            k8[rr] = LZ_REC_LOW8(x[rr]); slot[rr] = 0;
-            if (li < nt) { rec[li] = x[rr]; slot[rr] = atomicAdd(&cnt[w][k8[rr]], 1u); }
+            const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
+            slot[rr] = (li < nt) ? atomicAdd(&cnt[w][LZ_REC_LOW8(x[rr])], 1u) : 0u;
         }
         __syncthreads();
-        // offsets: bucket-major, then wave order inside a bucket
-        const u32 c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
-        const u32 mine = c0 + c1 + c2 + c3;
+        LZ_CLK(17);
+        // offsets: bucket-major, wave order inside a bucket
+        u32 mine = 0;
+        if (tid < LZ_NBIN) for (u32 k = 0; k < LZ_ST_WAVES; k++) { const u32 v = cnt[k][tid]; cnt[k][tid] = mine; mine += v; }
         const u32 beg = lz_exscan256(mine, wtot);
-        cnt[0][tid] = beg; cnt[1][tid] = beg + c0; cnt[2][tid] = beg + c0 + c1; cnt[3][tid] = beg + c0 + c1 + c2;
+        if (tid < LZ_NBIN) { for (u32 k = 0; k < LZ_ST_WAVES; k++) cnt[k][tid] += beg; lbeg[tid] = beg; lcnt[tid] = mine; }
         __syncthreads();
+        LZ_CLK(18);
 #pragma unroll
         for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
-            const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane;
-            if (li < nt) list[cnt[w][k8[rr]] + slot[rr]] = (unsigned short)li;
+            const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
+            if (li < nt) rec[cnt[w][LZ_REC_LOW8(x[rr])] + slot[rr]] = lz_rec_with_index(x[rr], li);
         }
         __syncthreads();
+        LZ_CLK(19);
         // the next tile's records are requested before this one is walked
         if (t0 + LZ_ST_TILE < r1) {
 #pragma unroll
-            for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (LZ_ST_TILE / 4) + (u32)rr * 64u + lane; x[rr] = ((u64)t0 + LZ_ST_TILE + li < (u64)r1) ? recs[(size_t)t0 + LZ_ST_TILE + li] : 0ull; }
+            for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane; x[rr] = ((u64)t0 + LZ_ST_TILE + li < (u64)r1) ? recs[(size_t)t0 + LZ_ST_TILE + li] : 0ull; }
         }
-        // Records a wave placed in the same step may sit in any order among themselves (the slots come from
-        // LDS atomics): the list is put in ascending tile order, which is discovery order, by an insertion pass
-        // (it is sorted already but for such neighbours).
-        for (u32 p = beg + 1; p < beg + mine; p++) {
-            const unsigned short v = list[p];
-            u32 q = p;
-            while (q > beg && list[q - 1] > v) { list[q] = list[q - 1]; q--; }
-            list[q] = v;
+        {
+            u32 p = walker ? lbeg[bucket] : 0u; const u32 end = walker ? p + lcnt[bucket] : 0u;
+            u32 ne = 0, nb = 0, prev = 0;                       // prev: tile index + 1 of the last record taken
+            for (;;) {
+                // every lane settles records from their phase-A summaries, LZ_ST_BATCH at a time, until one needs a
+                // real extension
+                bool pending = false; u32 pp2 = 0, ppay = 0;
+                bool disorder = false;
+                while (__ballot(p < end && !pending)) {         // straight-line batches: a lane that has stopped idles through selects
+                    u64 r[LZ_ST_BATCH];
+#pragma unroll
+                    for (int k = 0; k < LZ_ST_BATCH; k++) r[k] = rec[p + k];            // (reads past `end` stay inside rec[] and are not used)
+                    bool live = !pending && !disorder;
+                    u32 np = 0;
+#pragma unroll
+                    for (int k = 0; k < LZ_ST_BATCH; k++) {
+                        const u32 ix = LZ_REC_INDEX(r[k]) + 1u, p2 = LZ_REC_POS2(r[k]), pay = LZ_REC_PAYLOAD(r[k]);
+                        const bool in = live && (p + (u32)k < end);
+                        const bool bad = ix <= prev;                               // not in discovery order
+                        const bool drop = dend > p2 - L;                           // :1113
+                        const bool slow = LZ_REC_SLOW(r[k]) != 0 && !drop;
+                        const bool go = in && !bad && !slow;                       // the record is consumed here
+                        const bool fast = go && !drop;
+                        const u32 room = p2 - dend, dlo = pay & 0xFFu, dext = pay >> 8;
+                        const u32 extent = p2 + dext;                              // :2785
+                        ne += fast ? 1u : 0u;
+                        nb += fast ? (dlo < room ? dlo : room) + dext : 0u;        // :2818
+                        dend = (fast && extent > dend) ? extent : dend;
+                        prev = go ? ix : prev; np += go ? 1u : 0u;
+                        disorder = disorder || (in && bad);
+                        if (in && !bad && slow) { pending = true; pp2 = p2; ppay = pay; }
+                        live = go;
+                    }
+                    p += np;
+                    if (disorder) {                             // the rest of the list into ascending tile order (insertion sort)
+                        for (u32 a = p + 1; a < end; a++) {
+                            const u64 v = rec[a]; const u32 iv = LZ_REC_INDEX(v);
+                            u32 q = a;
+                            while (q > p && LZ_REC_INDEX(rec[q - 1]) > iv) { rec[q] = rec[q - 1]; q--; }
+                            rec[q] = v;
+                        }
+                        disorder = false;
+                    }
+                }
+                u64 mask = __ballot(pending);
+                LZ_CLK(20);
+                if (!mask) break;
+                while (mask) {                                  // the wave extends the pending hits, one at a time
+                    const int src = (int)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const u32 sp2 = (u32)__shfl((int)pp2, src), spay = (u32)__shfl((int)ppay, src), sdend = (u32)__shfl((int)dend, src);
+                    const u32 sh_ = blockIdx.x * LZ_NBIN + (u32)src * LZ_ST_WAVES + w;
+                    const s32 diag = (s32)((spay << 16) | sh_);
+                    const u32 pos1 = sp2 + (u32)diag;
+                    s32 stopl = (s32)sdend + diag;  if (stopl < 0) stopl = 0;                                     // :2612-2616
+                    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
+                    const LzCoopSide S = lz_coop_extend_wave(P, tab, pos1, diag, stopl, stopr, lane);
+                    const u32 l_stop = (u32)__shfl((int)S.stop_pos, 0), l_bpos = (u32)__shfl((int)S.best_pos, 0); const s32 l_best = __shfl(S.best, 0);
+                    const u32 r_stop = (u32)__shfl((int)S.stop_pos, 32), r_bpos = (u32)__shfl((int)S.best_pos, 32); const s32 r_best = __shfl(S.best, 32);
+                    if ((int)lane == src) {
+                        ne++; nb += r_stop - l_stop;                                             // :2818
+                        const u32 extent = (u32)((s32)r_stop - diag);                            // :2785
+                        if (extent > dend) dend = extent;
+                        const s32 sim = l_best + r_best;
+                        if (sim >= P.min_score) {
+                            const u32 oslot = atomicAdd(out_count, 1u);
+                            if (oslot < out_cap) { LzHspRec o; o.seed_pos1 = pos1; o.seed_pos2 = sp2; o.end1 = r_bpos; o.length = r_bpos - l_bpos; o.score = sim; out[oslot] = o; }
+                        }
+                        prev = LZ_REC_INDEX(rec[p]) + 1u;
+                        p++;
+                    }
+                    LZ_CLK(23);
+#if defined(LZ_PHASE_CLOCKS)
+                    if (threadIdx.x == 0) atomicAdd(&g_phase_clk[24], 1ull);
+#endif
+                }
+            }
+            n_ext += ne; n_bp += nb;
+            LZ_CLK(21);
         }
-        for (u32 p = beg; p < beg + mine; p++)
-            lz_settle_record(P, tab, rec[list[p]], h, dend, n_ext, n_bp, emit);
         __syncthreads();
+        LZ_CLK(22);
     }
-    diag_end[h] = dend;
+    if (walker) diag_end[h] = dend;
     for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
     if (lane == 0) {
         if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);

@@ -13,6 +13,7 @@
 #include "../../lastz_amd/csrc/lz_common.hpp"
 #include "../../lastz_amd/csrc/lz_host.hpp"
 #include "../../lastz_amd/csrc/lz_lut.hpp"
+#include "../../lastz_amd/csrc/lz_coop.hpp"
 
 struct Emul {
     std::vector<u8> traw, tcode;   // with LZ_SEQ_PAD either side
@@ -25,6 +26,26 @@ struct Emul {
     int last_scan_mode = -1;
 };
 static Emul E;
+
+// phase B's slow path as the device runs it: the wave-cooperative extension (lz_coop.hpp) instead of the serial
+// loops of lz_reextend; same contract
+template <class Emit>
+static u32 reextend_coop(const LzExtendParams& P, const s32* tab, u32 pos2, s32 diag, u32 dend, u64& n_bp, Emit&& emit)
+{
+    const u32 pos1 = pos2 + (u32)diag;
+    s32 stopl = (s32)dend + diag; if (stopl < 0) stopl = 0;
+    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;
+    auto score = [&](u32 i) { return tab[(LZ_CODE_CLASS(P.tcode[i]) << 5) | LZ_CODE_CLASS(P.qcode[(s32)i - diag])]; };
+    const LzCoopSide L = lz_coop_scan_host<false>(pos1, stopl, P.xdrop, score);
+    const LzCoopSide R = lz_coop_scan_host<true>(pos1, stopr, P.xdrop, score);
+    const u32 extent = (u32)((s32)R.stop_pos - diag);
+    if (extent > dend) dend = extent;
+    n_bp += (u64)(R.stop_pos - L.stop_pos);
+    const s32 sim = L.best + R.best;
+    if (sim >= P.min_score) { LzHspRec r; r.seed_pos1 = pos1; r.seed_pos2 = pos2; r.end1 = R.best_pos; r.length = R.best_pos - L.best_pos; r.score = sim; emit(r); }
+    return dend;
+}
+static u64 g_rx[4];   // profiling aid: re-extensions phase B runs, bases they scan, SLOW records, records
 
 static void encode(const std::vector<u8>& raw, std::vector<u8>& code, const u8 cls[256])
 {
@@ -128,7 +149,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
             for (int k = 0; k < 8; k++) {
                 const s64 i = (s64)j * 8 - LZ_PAD2 + k;
                 const u32 c = (i >= -(s64)LZ_SEQ_PAD && i < (s64)len + LZ_SEQ_PAD) ? code[(size_t)(i + LZ_SEQ_PAD)] : (u32)LZ_CODE_INVALID;
-                if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_CODE_BITS(c) << (2 * k);
+                if (c & LZ_CODE_INVALID) m |= 1u << k; else bits |= LZ_GRAY(LZ_CODE_BITS(c)) << (2 * k);
             }
             spc[j] = (u8)m; two[2 * j] = (u8)bits; two[2 * j + 1] = (u8)(bits >> 8);
         }
@@ -158,8 +179,8 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         std::vector<u64> rec(keys.size());
         for (size_t i = 0; i < keys.size(); i++) {
             u32 sm;
-            if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, M4, P.tlen, P.qlen, P.min_score, keys[i]);
-            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, M4, P.tlen, P.qlen, P.min_score, keys[i]);
+            if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, P.tlen, P.qlen, P.min_score, keys[i]);
+            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, P.tlen, P.qlen, P.min_score, keys[i]);
             else                     sm = lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]);
             rec[i] = lz_hit_record(keys[i], sm);
         }
@@ -170,14 +191,22 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         for (u32 bin = 0; bin < 256; bin++) {
             size_t p1 = p0;
             while (p1 < ord.size() && ((keys[ord[p1]] >> 40) & 0xFF) == bin) p1++;
-            for (size_t t0 = p0; t0 < p1; t0 += 2048) {
-                const size_t t1 = std::min(p1, t0 + 2048);
+            for (size_t t0 = p0; t0 < p1; t0 += 8192) {
+                const size_t t1 = std::min(p1, t0 + 8192);
                 std::vector<std::vector<u64>> lists(256);
                 for (size_t k = t0; k < t1; k++) lists[LZ_REC_LOW8(rec[ord[k]])].push_back(rec[ord[k]]);
                 for (u32 b = 0; b < 256; b++) {
                     const u32 h = bin * 256 + b;
-                    for (u64 r : lists[b])
+                    for (u64 r : lists[b]) {
+                        const u64 bp0 = n_bp, ex0 = n_ext;
+                        if (LZ_REC_SLOW(r) && !(diag_end[h] > LZ_REC_POS2(r) - P.seed_len) && !getenv("EMUL_SERIAL_REEXTEND")) {
+                            n_ext++;
+                            diag_end[h] = reextend_coop(P, tab, LZ_REC_POS2(r), (s32)((LZ_REC_PAYLOAD(r) << 16) | h), diag_end[h], n_bp,
+                                                        [&](const LzHspRec& x) { recs.push_back(x); });
+                        } else
                         lz_settle_record(P, tab, r, h, diag_end[h], n_ext, n_bp, [&](const LzHspRec& x) { recs.push_back(x); });
+                        g_rx[3]++; if (LZ_REC_SLOW(r)) { g_rx[2]++; if (n_ext != ex0) { g_rx[0]++; g_rx[1] += n_bp - bp0; } }
+                    }
                 }
             }
             p0 = p1;
@@ -200,6 +229,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     return 0;
 }
 extern "C" void emul_free(void* p) { free(p); }
+extern "C" void emul_reext_stats(u64* o) { for (int k = 0; k < 4; k++) o[k] = g_rx[k]; }
 extern "C" int emul_last_scan_mode() { return E.last_scan_mode; }
 
 // Self-test of the three block scanners on random class codes: the masked general scan

@@ -150,9 +150,9 @@ def test_lut_scans_with_dense_specials_and_short_sequences(em, seed):
         for s in rng.integers(0, n - 50, 60):
             arr[s:s + int(rng.integers(1, 40))] = ord("N")   # N runs
     _, masked = H.scoring()
-    for xd in (910, 400, 250):
+    for xd in (910, 400, 375):
         _check(em, t, q, masked=masked, xdrop=xd, hsp_threshold=2000, cap=30000)
         assert _mode(em) == 1
     _check(em, t[:300], q[:200], pattern="11111111", wt=0, hsp_threshold=800)          # everything within reach of an end
-    _check(em, t, q, xdrop=249, hsp_threshold=1500)         # two bases after a maximum set inside a group can lose 250 > xDrop: not eligible
+    _check(em, t, q, xdrop=374, hsp_threshold=1500)         # three bases after a maximum set inside a group can lose 375 > xDrop: not eligible
     assert _mode(em) == 2

@@ -177,10 +177,10 @@ def test_lut_scans_dense_specials_short_sequences(gpu, seed):
             arr[s:s + int(rng.integers(1, 40))] = ord("N")
     _, masked = H.scoring()
     tab = _prep(gpu, t)
-    for xd in (910, 400, 250, 249):
+    for xd in (910, 400, 375, 374):
         for _, _, qq in H.strands(q):
             _same_hsps(gpu, tab, qq, masked, xdrop=xd, hsp_threshold=2000)
-        assert gpu.last_scan_mode() == (1 if xd >= 250 else 2)
+        assert gpu.last_scan_mode() == (1 if xd >= 375 else 2)
     tab = _prep(gpu, t[:300], "11111111", 0)
     _same_hsps(gpu, tab, q[:200], masked, hsp_threshold=800)
 
