@@ -107,6 +107,15 @@ int lzgpu_table_geom(lz_table_geom* out);
 int lzgpu_table_adopt(const lz_table_geom* geom);
 int lzgpu_table_buffers(void* dev_ptr[3], uint64_t bytes[3]);   /* target bytes, wstart, wpos */
 int lzgpu_table_commit(void);
+/* The whole exchange in one call, for callers that have no communicator of their own (the reference-side
+ * binding, integration/lzgpu_shim.c, when lastz runs as one process per GPU): every rank of `world` calls
+ * lzgpu_table_share(rank, world, dir) at the same point; rank 0 must hold a table (lzgpu_table_prepare), the
+ * others receive its geometry (written to <dir>/geom by rank 0), adopt it, receive the three buffers and commit.
+ * Transport: RCCL over xGMI (ncclBroadcast, librccl loaded on first use; the unique id travels through
+ * <dir>/nccl_id), or -- LZGPU_SHARE_TRANSPORT=file, for ranks that share one device, where RCCL refuses to
+ * run -- through files in <dir> (host staging; tests only).  `dir` must be a directory all ranks see and that
+ * is empty at the start of the run. */
+int lzgpu_table_share(int rank, int world, const char* dir);
 /* device-to-device copy on the library's stream (lets a caller that received the broadcast in
  * its own allocation hand it over without knowing which HIP runtime object owns the stream). */
 int lzgpu_device_copy(void* dst_dev, const void* src_dev, uint64_t bytes);

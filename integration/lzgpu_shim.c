@@ -59,6 +59,58 @@ static void note (const char* what, const char* how)
 
 static void drop_device_table (void) { devTable = NULL;  devTargetV = NULL;  devTargetLen = 0; }
 
+/* ---- one process per GPU (lastz_amd/multi.py launches them): LZGPU_RANK / LZGPU_WORLD name this process,
+ * LZGPU_SHARE_DIR is a directory all ranks see (the table rendezvous), LZGPU_UNIT_PLAN a text file of
+ * "contig strand rank" lines that deals the (query sequence, strand) units out to the ranks.  Every rank runs the
+ * same command on the same files; a unit a rank does not own yields no HSPs there, so that its output holds the
+ * stanzas of its own units only, and the launcher merges the ranks' outputs in file order (queries in file
+ * order, + strand before - strand: src/lastz.c:1592-1691). */
+static int    mgRank = -1, mgWorld = 1, mgTables = 0;
+static char*  mgDir = NULL;
+static int*   mgPlan = NULL;   static u32 mgPlanLen = 0;        /* [2*(contig-1) + strand] -> rank */
+
+static void multi_init (void)
+	{
+	char* e;  FILE* f;  unsigned c, st, r;
+	if (mgRank >= 0) return;
+	mgRank = 0;
+	if ((e = getenv ("LZGPU_WORLD")) != NULL) mgWorld = atoi (e);
+	if (mgWorld < 1) mgWorld = 1;
+	if ((e = getenv ("LZGPU_RANK")) != NULL) mgRank = atoi (e);
+	if ((mgRank < 0) || (mgRank >= mgWorld)) suicidef ("LZGPU_RANK=%d is not in [0,%d)", mgRank, mgWorld);
+	mgDir = getenv ("LZGPU_SHARE_DIR");
+	if (((mgWorld > 1) || (getenv ("LZGPU_SHARE_FORCE") != NULL)) && (mgDir == NULL)) suicide ("LZGPU_WORLD > 1 needs LZGPU_SHARE_DIR");
+	if ((mgWorld > 1) && ((e = getenv ("LZGPU_UNIT_PLAN")) != NULL))
+		{
+		f = fopen_or_die (e, "rt");
+		while (fscanf (f, "%u %u %u", &c, &st, &r) == 3)
+			{
+			u32 ix = 2*(c-1) + (st & 1);
+			if ((c < 1) || (r >= (unsigned) mgWorld)) suicidef ("bad line in %s", e);
+			if (ix >= mgPlanLen)
+				{
+				u32 n = 2*ix + 16, k;
+				mgPlan = (int*) realloc_or_die ("lzgpu unit plan", mgPlan, n * sizeof(int));
+				for (k=mgPlanLen ; k<n ; k++) mgPlan[k] = -1;
+				mgPlanLen = n;
+				}
+			mgPlan[ix] = (int) r;
+			}
+		fclose_if_valid (f);
+		}
+	}
+
+static int unit_is_mine (seq* seq2)
+	{
+	u32 contig, ix;
+	multi_init ();
+	if (mgWorld <= 1) return true;
+	contig = (seq2->contig >= 1)? seq2->contig : 1;
+	ix = 2*(contig-1) + (((seq2->revCompFlags & rcf_rev) != 0)? 1 : 0);
+	if ((ix < mgPlanLen) && (mgPlan[ix] >= 0)) return (mgPlan[ix] == mgRank);
+	return ((int) (ix % (u32) mgWorld) == mgRank);                      /* no plan: round robin */
+	}
+
 static int fast_seed (seed* hitSeed, lz_seed_desc* sd)
 	{
 	int i, j, nf, np;
@@ -107,11 +159,23 @@ postable* build_seed_position_table
 		{ note ("table", "reference path");       /* (e.g. the tweener's small windows; the device keeps the main table) */
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
 
-	rc = lzgpu_table_prepare (seq->v, seq->len, start, e, upperCharToBits, &sd, step);
+	multi_init ();
+	if ((mgWorld > 1) && (mgRank != 0)) rc = 0;                    /* the table comes from rank 0 */
+	else rc = lzgpu_table_prepare (seq->v, seq->len, start, e, upperCharToBits, &sd, step);
 	if (rc < 0) suicidef ("lzgpu_table_prepare: %s", lzgpu_last_error());
+	if ((rc > 0) && (mgWorld > 1)) suicidef ("lzgpu_table_prepare declined (%d) in a multi-process run", rc);
 	if (rc > 0)
 		{ note ("table", "declined, reference path");  drop_device_table ();
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
+	if ((mgWorld > 1) || (getenv ("LZGPU_SHARE_FORCE") != NULL))
+		{
+		char dir[1024];                                            /* one rendezvous directory per table of the run */
+		snprintf (dir, sizeof(dir), "%s/table%d", mgDir, mgTables++);
+		if (mgRank == 0) { char cmd[1100];  snprintf (cmd, sizeof(cmd), "mkdir -p '%s'", dir);  if (system (cmd) != 0) suicidef ("cannot create %s", dir); }
+		rc = lzgpu_table_share (mgRank, mgWorld, dir);
+		if (rc != 0) suicidef ("lzgpu_table_share: %s", lzgpu_last_error());
+		note ("table", (mgRank == 0)? "shared with the other ranks" : "received from rank 0");
+		}
 
 	/* host copy in the reference's layout: capsule writer, masking, --tableonly keep working */
 	pt = new_position_table (hitSeed->weight, start, e, step, true, true, false);
@@ -157,6 +221,9 @@ u64 seed_hit_search
 		{ note ("search", "reference path");
 		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
 		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
+
+	if (!unit_is_mine (seq2))
+		{ note ("search", "unit of another rank");  empty_diag_hash ();  return 0; }
 
 	memset (&a, 0, sizeof(a));
 	a.query = seq2->v;  a.qlen = seq2->len;  a.query_slot = -1;

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblzgpu.so")
-SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "lz_host.cpp", "lz_gapped_host.cpp"]
+SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "lz_share.hip", "lz_host.cpp", "lz_gapped_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("LZGPU_CXXFLAGS", "").split()
 
 
@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     if force or procs or _stale(out, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

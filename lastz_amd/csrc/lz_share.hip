@@ -1,0 +1,112 @@
+// lz_share.hip -- lzgpu_table_share (include/lzgpu.h): the position table of rank 0 on every rank of a
+// one-process-per-GPU run, for callers without a communicator of their own (the lastz binding).
+// The data path is one ncclBroadcast per table buffer over RCCL / xGMI; librccl is loaded on first use so
+// that single-GPU runs never touch it.  Rendezvous (geometry, the RCCL unique id) goes through small files
+// in a directory all ranks see.  LZGPU_SHARE_TRANSPORT=file replaces the broadcast by host staging through
+// that directory: for ranks that share ONE device (tests on a one-GPU box), where RCCL refuses to run.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <string>
+#include <vector>
+#include "lz_ctx.hpp"
+
+namespace {
+struct NcclUid { char internal[128]; };
+typedef int (*fn_get_uid)(NcclUid*);
+typedef int (*fn_init_rank)(void** comm, int nranks, NcclUid id, int rank);
+typedef int (*fn_bcast)(const void* send, void* recv, size_t count, int dtype, int root, void* comm, hipStream_t s);
+typedef int (*fn_destroy)(void* comm);
+typedef const char* (*fn_errstr)(int);
+
+bool write_file_atomic(const std::string& path, const void* p, size_t n)
+{
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(p, 1, n, f) == n;
+    fclose(f);
+    return ok && rename(tmp.c_str(), path.c_str()) == 0;
+}
+bool read_file_wait(const std::string& path, void* p, size_t n, int timeout_s)
+{
+    for (int t = 0; t < timeout_s * 100; t++) {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (f) { const bool ok = fread(p, 1, n, f) == n; fclose(f); if (ok) return true; }
+        usleep(10000);
+    }
+    return false;
+}
+}
+
+extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
+{
+    LzCtx& c = lz_ctx();
+    if (world <= 1 && !getenv("LZGPU_SHARE_FORCE")) return 0;   // (LZGPU_SHARE_FORCE: a one-rank run still goes through the transport -- tests)
+    if (world < 1) world = 1;
+    if (rank < 0 || rank >= world || !dir) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_share: bad rank / world / directory");
+    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    const std::string d(dir);
+    const char* tr = getenv("LZGPU_SHARE_TRANSPORT");
+    const bool by_file = tr && strcmp(tr, "file") == 0;
+    const int wait_s = 600;
+    int rc;
+
+    // ---- geometry
+    lz_table_geom g;
+    if (rank == 0) {
+        if ((rc = lzgpu_table_geom(&g))) return rc;
+        if (!write_file_atomic(d + "/geom", &g, sizeof(g))) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: cannot write %s/geom", dir);
+    } else {
+        if (!read_file_wait(d + "/geom", &g, sizeof(g), wait_s)) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: no geometry from rank 0 in %s", dir);
+        if ((rc = lzgpu_table_adopt(&g))) return rc;
+    }
+    void* ptr[3]; uint64_t bytes[3];
+    if ((rc = lzgpu_table_buffers(ptr, bytes))) return rc;
+
+    if (by_file) {
+        for (int k = 0; k < 3; k++) {
+            const std::string path = d + "/buf" + std::to_string(k);
+            std::vector<char> host(bytes[k] ? bytes[k] : 1);
+            if (rank == 0) {
+                if (bytes[k]) LZ_HIP(hipMemcpy(host.data(), ptr[k], bytes[k], hipMemcpyDeviceToHost));
+                if (!write_file_atomic(path, host.data(), bytes[k])) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: cannot write %s", path.c_str());
+            } else {
+                if (!read_file_wait(path, host.data(), bytes[k], wait_s)) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: %s did not arrive", path.c_str());
+                if (bytes[k]) LZ_HIP(hipMemcpy(ptr[k], host.data(), bytes[k], hipMemcpyHostToDevice));
+            }
+        }
+    } else {
+        static void* lib = nullptr;
+        static fn_get_uid get_uid; static fn_init_rank init_rank; static fn_bcast bcast; static fn_destroy destroy; static fn_errstr errstr;
+        if (!lib) {
+            lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: librccl not found (%s)", dlerror());
+            get_uid = (fn_get_uid)dlsym(lib, "ncclGetUniqueId"); init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+            bcast = (fn_bcast)dlsym(lib, "ncclBroadcast"); destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy"); errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+            if (!get_uid || !init_rank || !bcast || !destroy) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: librccl lacks a symbol");
+        }
+        // RCCL announces itself on stdout: the caller's stdout is its output file (lastz writes alignments there)
+        fflush(stdout);
+        const int saved_out = dup(1);
+        if (saved_out >= 0) (void)dup2(2, 1);
+        struct Restore { int fd; ~Restore() { if (fd >= 0) { fflush(stdout); (void)dup2(fd, 1); close(fd); } } } restore{ saved_out };
+        NcclUid id; int e;
+        if (rank == 0) {
+            if ((e = get_uid(&id))) return lz_fail(LZGPU_ERR_HIP, "ncclGetUniqueId: %s", errstr ? errstr(e) : "?");
+            if (!write_file_atomic(d + "/nccl_id", &id, sizeof(id))) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: cannot write %s/nccl_id", dir);
+        } else if (!read_file_wait(d + "/nccl_id", &id, sizeof(id), wait_s)) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_share: no RCCL id from rank 0");
+        void* comm = nullptr;
+        if ((e = init_rank(&comm, world, id, rank))) return lz_fail(LZGPU_ERR_HIP, "ncclCommInitRank: %s", errstr ? errstr(e) : "?");
+        for (int k = 0; k < 3; k++)
+            if (bytes[k] && (e = bcast(ptr[k], ptr[k], (size_t)bytes[k], /*ncclUint8*/ 1, 0, comm, c.stream))) { destroy(comm); return lz_fail(LZGPU_ERR_HIP, "ncclBroadcast: %s", errstr ? errstr(e) : "?"); }
+        LZ_HIP(hipStreamSynchronize(c.stream));
+        destroy(comm);
+    }
+    if (rank != 0 && (rc = lzgpu_table_commit())) return rc;
+    return 0;
+}

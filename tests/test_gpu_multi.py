@@ -1,0 +1,75 @@
+"""BASELINE.json configs[3] and [4] in their shape: one lastz process per GPU rank (here: two ranks on the one GPU
+of the test box, table handed over through lzgpu_table_share's file transport because RCCL refuses two ranks on
+one device), (query sequence x strand) units dealt out by LPT, outputs merged in the reference's order -- byte for
+byte the single-process output and the pristine reference's; with --chain --inner=2000 --scores=HOXD70 on top
+(configs[4]).  The RCCL transport itself is exercised with one rank (unique id, communicator, ncclBroadcast on the
+library's stream)."""
+import os
+import subprocess
+import pytest
+
+from lastz_amd import seqio, multi
+import helpers as H
+from lavparse import normalize_lav
+
+pytestmark = pytest.mark.gpu
+GPU_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz_gpu")
+REF_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz")
+HOXD70 = os.path.join(H.ROOT, "lastz_amd", "data", "HOXD70.q")
+needs_bins = pytest.mark.skipif(not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)), reason="oracle/_ref binaries not built")
+
+
+@pytest.fixture(scope="module")
+def pair(tmp_path_factory):
+    d = tmp_path_factory.mktemp("multi")
+    t, q = seqio.synth_pair(1_500_000, 1_400_000, seed=73)
+    _, q2 = seqio.synth_pair(1_500_000, 400_000, seed=74)
+    seqio.write_fasta(d / "t.fa", [("target", t)])
+    seqio.write_fasta(d / "q.fa", [("qa", q[:600_000]), ("qb", q2), ("qc", q[600_000:])])     # three query sequences
+    return d
+
+
+def _run(binary, args, cwd, env_extra=None):
+    env = dict(os.environ); env.update(env_extra or {})
+    p = subprocess.run([binary] + args, cwd=cwd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return p.stdout, p.stderr
+
+
+CONFIGS = {"configs3_gapped": ["--ydrop=9430"],
+           "configs4_chain_inner_scores": ["--chain", "--inner=2000", "--scores=" + HOXD70]}
+
+
+@needs_bins
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_two_ranks_merge_to_the_single_process_and_reference_output(pair, name):
+    flags = CONFIGS[name]
+    t, q = str(pair / "t.fa"), str(pair / "q.fa")
+    merged, errs, plan = multi.run(t, q, flags, ranks=2, lastz=GPU_BIN, devices=[0, 0], transport="file",
+                                   env={"LZGPU_VERBOSE": "1"})
+    single, err1 = _run(GPU_BIN, [t, q] + flags, pair, {"LZGPU_VERBOSE": "1"})
+    ref, _ = _run(REF_BIN, [t, q] + flags, pair)
+    assert normalize_lav(merged) == normalize_lav(single)
+    assert normalize_lav(merged) == normalize_lav(ref)
+    assert merged.count("\na {") > 20
+    # both ranks worked, each on its own units, and the hot path ran on the GPU
+    assert sorted(u for p in plan for u in p) == [(i, s) for i in range(3) for s in (0, 1)] and all(plan)
+    assert "[lzgpu] table: shared with the other ranks" in errs[0] and "[lzgpu] table: received from rank 0" in errs[1]
+    for r in (0, 1):
+        assert errs[r].count("[lzgpu] search: done on the GPU") == len(plan[r])
+        assert errs[r].count("[lzgpu] search: unit of another rank") == 6 - len(plan[r])
+        assert "[lzgpu] gapped: done on the GPU" in errs[r]
+    assert "[lzgpu] gapped: done on the GPU" in err1
+
+
+@needs_bins
+def test_rccl_transport_with_one_rank(pair):
+    """librccl loaded on demand, unique id through the rendezvous directory, communicator, one ncclBroadcast per
+    table buffer on the library's stream -- all of lzgpu_table_share's RCCL path that a one-GPU box can run"""
+    share = pair / "share1"; os.makedirs(share, exist_ok=True)
+    out, err = _run(GPU_BIN, [str(pair / "t.fa"), str(pair / "q.fa"), "--nogapped"], pair,
+                    {"LZGPU_VERBOSE": "1", "LZGPU_SHARE_FORCE": "1", "LZGPU_SHARE_DIR": str(share), "LZGPU_RANK": "0", "LZGPU_WORLD": "1"})
+    ref, _ = _run(REF_BIN, [str(pair / "t.fa"), str(pair / "q.fa"), "--nogapped"], pair)
+    assert "[lzgpu] table: shared with the other ranks" in err
+    assert os.path.exists(share / "table0" / "nccl_id") and os.path.exists(share / "table0" / "geom")
+    assert normalize_lav(out) == normalize_lav(ref)
