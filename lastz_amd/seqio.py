@@ -83,6 +83,18 @@ def synth_pair(tlen, qlen, seed=1, homolog_frac=0.5, sub_rate=0.12, indel_rate=0
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     target = acgt[rng.integers(0, 4, tlen)]
+    return target, _query_of(rng, target, qlen, homolog_frac, sub_rate, indel_rate, block_min, block_max, revcomp_frac)
+
+
+def synth_query(target, qlen, seed, homolog_frac=0.5, sub_rate=0.12, indel_rate=0.01,
+                block_min=2000, block_max=20000, revcomp_frac=0.5):
+    """another query for an existing target (multi-sequence query sets: BASELINE.json configs[3]), same recipe"""
+    return _query_of(np.random.default_rng(seed), target, qlen, homolog_frac, sub_rate, indel_rate, block_min, block_max, revcomp_frac)
+
+
+def _query_of(rng, target, qlen, homolog_frac, sub_rate, indel_rate, block_min, block_max, revcomp_frac):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    tlen = len(target)
     parts, have = [], 0
     while have < qlen:
         blen = int(rng.integers(block_min, block_max + 1))
@@ -96,5 +108,4 @@ def synth_pair(tlen, qlen, seed=1, homolog_frac=0.5, sub_rate=0.12, indel_rate=0
             blk = acgt[rng.integers(0, 4, blen)]
         parts.append(blk)
         have += len(blk)
-    query = np.concatenate(parts)[:qlen].copy()
-    return target, query
+    return np.concatenate(parts)[:qlen].copy()

@@ -41,8 +41,9 @@ def main(tlen=50_000_000, qlen=50_000_000, seed=1000, workdir="/tmp/bench50m"):
         t, q = seqio.synth_pair(tlen, qlen, seed=seed)
         seqio.write_fasta(tf, [("target", t)]); seqio.write_fasta(qf, [("query", q)])
     t0 = time.time()
-    p1 = subprocess.Popen([REF, tf, qf, "--nogapped", HSP_FMT], stdout=open(os.path.join(workdir, "hsp.tsv"), "wb"))
-    p2 = subprocess.Popen([REF, tf, qf, "--ydrop=9430"], stdout=open(os.path.join(workdir, "gapped.lav"), "wb"))
+    # (the LAV s-stanzas quote the file names as given: relative names, run from the directory)
+    p1 = subprocess.Popen([REF, "t.fa", "q.fa", "--nogapped", HSP_FMT], stdout=open(os.path.join(workdir, "hsp.tsv"), "wb"), cwd=workdir)
+    p2 = subprocess.Popen([REF, "t.fa", "q.fa", "--ydrop=9430"], stdout=open(os.path.join(workdir, "gapped.lav"), "wb"), cwd=workdir)
     assert p1.wait() == 0
     t1 = time.time() - t0
     assert p2.wait() == 0

@@ -107,3 +107,17 @@ def test_real_dna_soft_masked_2bit(sandbox, args):
     assert len(a) > 500
     if "--self" not in args:
         assert "[lzgpu] table: built on the GPU" in err and "[lzgpu] search: done on the GPU" in err
+
+
+@needs_bins
+def test_bench_pair_lav_fingerprint(tmp_path):
+    """BASELINE.json configs[2] at full size: the LAV that lastz_gpu writes for the 50 Mbp x 50 Mbp bench pair has the
+    SHA-256 of the pristine reference's (tests/golden/bench50m.sha.json; the reference needs 40 minutes for it)"""
+    import json, bench
+    gold = json.load(open(os.path.join(H.GOLDEN, "bench50m.sha.json")))
+    t, q = seqio.synth_pair(gold["tlen"], gold["qlen"], seed=gold["seed"])
+    seqio.write_fasta(tmp_path / "t.fa", [("target", t)]); seqio.write_fasta(tmp_path / "q.fa", [("query", q)])
+    out, err = run(GPU_BIN, ["t.fa", "q.fa", "--ydrop=9430"], tmp_path, {"LZGPU_VERBOSE": "1"})
+    assert err.count("[lzgpu] gapped: done on the GPU") == 2 and err.count("[lzgpu] search: done on the GPU") == 2
+    assert out.count("\na {") == gold["lav_blocks"]
+    assert bench.lav_fingerprint(out) == gold["lav_sha"]

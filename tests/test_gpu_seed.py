@@ -242,12 +242,18 @@ def test_full_size_properties(gpu):
     """BASELINE.json configs[1] size (50 Mbp x 50 Mbp, one strand): properties that do not
     need the oracle -- determinism, chunk-capacity invariance, every HSP re-scores to its score on
     the host, HSPs arrive in discovery-compatible order, counters obey H >= E >= HSPs."""
-    t, q = seqio.synth_pair(50_000_000, 50_000_000, seed=4)
+    t, q = seqio.synth_pair(50_000_000, 50_000_000, seed=1000)        # the exact pair bench.py times
     sub, masked = H.scoring()
     _prep(gpu, t)
     gpu.counters_reset()
     a = gpu.seed_hit_search(masked, q=q)
     c = gpu.counters()
+    # ... and one check that does: the SHA-256 of the pristine reference's HSP list for this pair, both strands
+    # (tests/golden/bench50m.sha.json, made by tests/golden/make_bench_sha.py in 40 minutes of CPU)
+    import json, bench
+    gold = json.load(open(os.path.join(H.GOLDEN, "bench50m.sha.json")))
+    sha, rows = bench.hsp_rows_sha([a, gpu.seed_hit_search(masked, q=seqio.revcomp(q))])
+    assert rows == gold["hsp_rows"] and sha == gold["hsp_sha"]
     gpu.set_hit_capacity(1 << 26)
     b = gpu.seed_hit_search(masked, q=q)
     gpu.set_hit_capacity(1 << 28)
