@@ -204,6 +204,8 @@ typedef struct lz_counters {       /* same events as the reference's collect_sta
     uint64_t dp_cells;             /* "DP cells visited"  src/gapped_extend.c:3599,3778           */
     uint64_t gapped_extensions;    /* one-sided DPs run (including speculative re-runs)           */
     uint64_t anchors_extended;
+    uint64_t truncated_extensions; /* one-sided DPs that ran out of traceback space (the reference warns
+                                      "truncating alignment ...", src/gapped_extend.c:3640-3661)    */
 } lz_counters;
 void lzgpu_counters_reset(void);
 int  lzgpu_counters_get(lz_counters* out);

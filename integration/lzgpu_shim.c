@@ -188,7 +188,7 @@ postable* build_seed_position_table
 	}
 
 void free_position_table (postable* pt)
-	{ if (pt == devTable) devTable = NULL;  ref_free_position_table (pt); }
+	{ if (pt == devTable) drop_device_table ();  ref_free_position_table (pt); }   /* (lastz reuses seq->v for the next target: the device copy is stale from here on) */
 
 void mask_seed_position_table
    (postable* pt, seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed)
@@ -319,6 +319,17 @@ alignel* gapped_extend
 		if (head == NULL) head = last = el;  else { last->next = el;  last = el; }
 		}
 	lzgpu_free (al);  lzgpu_free (ops);
+	{ /* the reference warns when an extension runs out of traceback space (src/gapped_extend.c:3640-3661) */
+	static uint64_t warned = 0;
+	lz_counters cn;
+	if ((lzgpu_counters_get (&cn) == 0) && (cn.truncated_extensions > warned))
+		{
+		fprintf (stderr, "WARNING. %llu gapped extension(s) of %s vs %s were truncated for lack of traceback space;"
+		                 " use --allocate:traceback (see the lastz documentation) to give the DP more room.\n",
+		                 (unsigned long long) (cn.truncated_extensions - warned), seq1->header? seq1->header : "target", seq2->header? seq2->header : "query");
+		warned = cn.truncated_extensions;
+		}
+	}
 	note ("gapped", "done on the GPU");
 	return head;
 	}

@@ -353,6 +353,7 @@ extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint
     c.counters.anchors_extended += st.anchors_extended;
     c.counters.dp_cells += st.dp_cells;                 // cells of the DPs the reference would have run
     c.counters.gapped_extensions += st.dp_runs;         // DPs actually launched (speculation included)
+    c.counters.truncated_extensions += st.truncated;
     if (rc) return rc < 0 ? lz_fail(rc, "gapped_extend failed") : rc;
     *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
     *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);

@@ -273,7 +273,19 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 {
     out.clear(); out_ops.clear();
     memset(&st, 0, sizeof(st));
-    if (G.tlen == G.qlen && memcmp(G.t, G.q, G.tlen) == 0) return LZGPU_NH_IDENTICAL;   // :1152-1189 not restated
+    // identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() of the bytes and, on a match, puts the
+    // trivial self-alignment in front of every anchor (:1152-1189, not restated here): such a pair is declined.  The
+    // test here folds the case of every ASCII letter -- a superset of dna_toupper's, so it can only decline more.
+    if (G.tlen == G.qlen) {
+        u32 i = 0;
+        for (; i < G.tlen; i++) {
+            u8 a = G.t[i], b = G.q[i];
+            if (a >= 'a' && a <= 'z') a -= 32;
+            if (b >= 'a' && b <= 'z') b -= 32;
+            if (a != b) break;
+        }
+        if (i == G.tlen) return LZGPU_NH_IDENTICAL;
+    }
     if (G.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
 
     // LZGPU_HOSTPROF=1: where the host time of the stage goes
@@ -415,6 +427,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (!same) { cache.erase(it); next = aix; cut = true; st.reruns++; break; }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
+            st.truncated += (rl.truncated ? 1 : 0) + (rr.truncated ? 1 : 0);     // :3640-3661: the reference warns on stderr
             Built b;
             splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, b);
             cache.erase(it);

@@ -37,7 +37,7 @@ struct LzGappedParams {
     u32 window;                            // max anchors speculated per round
 };
 
-struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns; };
+struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };
 
 void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* segs, u32 n);
 

@@ -18,8 +18,11 @@
 // Table index.  The 2-bit codes are stored Gray-coded (A=0, C=1, G=3, T=2) so that for every matrix that is
 // invariant under complementing both bases (M[a][b] == M[3-a][3-b]: every strand-symmetric DNA matrix, HOXD70
 // included) the score depends on x = t ^ q and the low bit of t only: 3 bits per base, 12 bits per group of
-// four, 4096 entries of 8 bytes per scan direction.  Four bases are one byte of the code stream, so that a
-// group's index is one byte of (t ^ q) and one nibble of the compressed low-bit plane of t.
+// four, 4096 entries of 8 bytes.  Four bases are one byte of the code stream, so that a group's index is one byte
+// of (t ^ q) and one nibble of the compressed low-bit plane of t.  There is ONE table, for bases consumed in
+// ascending order: the window of a left scan is turned around when it is fetched (the 16 bytes that end at the
+// scan position, base order reversed: v_bfrev + a swap of neighbouring bits per word), after which loop 1 is loop 2
+// on the mirrored strings -- 32 KiB of LDS instead of 64, which is what lets two workgroups share a CU.
 //
 // Bytes outside the 2-bit alphabet ("specials": lower case, N, the NUL between partitions, ...) are kept in a
 // separate 1-bit-per-base mask.  The LUT path is only taken when every special byte that OCCURS in the two
@@ -50,7 +53,11 @@ struct LzLutScan { u32 s; s32 run, best; u32 room, used, alive, nwin; };   // al
 
 #if defined(__HIP_DEVICE_COMPILE__)
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#if defined(LZ_EXPERIMENT_NODOT)                                // timing experiment only (wrong results): what the v_dot4 pair costs
+LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return acc + (s32)a; }
+#else
 LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return __builtin_amdgcn_sdot4((int)a, 0x01010101, acc, false); }
+#endif
 LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k)    // (byte k of hi_src) << 8 | byte k of lo_src
 { return __builtin_amdgcn_perm(hi_src, lo_src, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k); }
 #define LZ_UNROLL_ALL _Pragma("unroll")
@@ -66,14 +73,28 @@ LZ_HD u32 lz_clz64(u64 x) { return (u32)__builtin_clzll(x); }
 // the raw bytes of one window: 16 bytes of each code stream (+ 16 bytes of each special mask)
 template <bool SPECIAL> struct LzLutRaw { LzVec16 tv, qv, tm, qm; };
 template <> struct LzLutRaw<false> { LzVec16 tv, qv; };
-// group g of a window is byte g of the aligned stream (RIGHT: base s at bit 0) / byte 14 - g (LEFT: base s-1 at
-// bits 118-119: the 16 bytes that end with the byte of base s-1, shifted right by 2r' + 2 bits)
+// group g of a window is byte g of the aligned stream: base s (RIGHT) resp. base s-1 (LEFT, mirrored) at bit 0.
+LZ_HD u32 lz_pairrev32(u32 x)                                   // the 16 two-bit codes of a word in reverse order
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 y = __builtin_bitreverse32(x);
+#else
+    u32 y = 0; for (int k = 0; k < 32; k++) y |= ((x >> k) & 1u) << (31 - k);
+#endif
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
 template <bool RIGHT, bool SPECIAL>
 LZ_HD void lz_lut_fetch(const LzLutParams& P, u32 s_, s32 diag, LzLutRaw<SPECIAL>& raw)
 {
     const s64 s = (s64)s_, sq = s - (s64)diag;
     if (RIGHT) { raw.tv = lz_load16(P.t2 + ((u64)(s + LZ_PAD2) >> 2)); raw.qv = lz_load16(P.q2 + ((u64)(sq + LZ_PAD2) >> 2)); }
-    else       { raw.tv = lz_load16(P.t2 + ((u64)(s - 1 + LZ_PAD2) >> 2) - 15); raw.qv = lz_load16(P.q2 + ((u64)(sq - 1 + LZ_PAD2) >> 2) - 15); }
+    else {
+        // the 16 bytes that end with the byte of base s-1, mirrored: that base (pair 60 + r' of the 64 loaded) becomes
+        // pair 3 - r', which lz_lut_window's right shift of 2 (3 - r') bits brings to bit 0
+        const LzVec16 a = lz_load16(P.t2 + ((u64)(s - 1 + LZ_PAD2) >> 2) - 15), b = lz_load16(P.q2 + ((u64)(sq - 1 + LZ_PAD2) >> 2) - 15);
+        LZ_UNROLL_ALL
+        for (int k = 0; k < 4; k++) { raw.tv.w[k] = lz_pairrev32(a.w[3 - k]); raw.qv.w[k] = lz_pairrev32(b.w[3 - k]); }
+    }
     if constexpr (SPECIAL) {
         if (RIGHT) { raw.tm = lz_load16(P.tsp + ((u64)(s + LZ_PAD2) >> 3)); raw.qm = lz_load16(P.qsp + ((u64)(sq + LZ_PAD2) >> 3)); }
         else       { raw.tm = lz_load16(P.tsp + ((u64)(s - 1 + LZ_PAD2) >> 3) - 14); raw.qm = lz_load16(P.qsp + ((u64)(sq - 1 + LZ_PAD2) >> 3) - 14); }
@@ -91,7 +112,7 @@ LZ_HD u64 lz_lut_mask64(const LzVec16& v, s64 s)
     return ((u64)lz_alignbit(v.w[3], v.w[2], k) << 32) | lz_alignbit(v.w[2], v.w[1], k);
 }
 
-// One 16-byte window (up to 60 bases = 15 groups) of one scan.  lut = this direction's table.
+// One 16-byte window (up to 60 bases = 15 groups) of one scan.  lut = the table (lzh_lut_build).
 // LIMCHK == false: the caller guarantees 60 plain bases (st.room >= 60, no special byte in reach): the limit tests
 // drop out of the straight-line part and the stopping group needs no general walk.
 // On return st.alive says whether the scan goes on into the next window.
@@ -102,8 +123,8 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     const s64 s = (s64)st.s, sq = s - (s64)diag;
     u32 tw[4], qw[4];
     {
-        const u32 a = RIGHT ? 2u * (u32)((u64)(s + LZ_PAD2) & 3u) : 2u * (u32)((u64)(s - 1 + LZ_PAD2) & 3u) + 2u;
-        const u32 b = RIGHT ? 2u * (u32)((u64)(sq + LZ_PAD2) & 3u) : 2u * (u32)((u64)(sq - 1 + LZ_PAD2) & 3u) + 2u;
+        const u32 a = RIGHT ? 2u * (u32)((u64)(s + LZ_PAD2) & 3u) : 2u * (3u - (u32)((u64)(s - 1 + LZ_PAD2) & 3u));
+        const u32 b = RIGHT ? 2u * (u32)((u64)(sq + LZ_PAD2) & 3u) : 2u * (3u - (u32)((u64)(sq - 1 + LZ_PAD2) & 3u));
         tw[0] = lz_alignbit(raw.tv.w[1], raw.tv.w[0], a); tw[1] = lz_alignbit(raw.tv.w[2], raw.tv.w[1], a); tw[2] = lz_alignbit(raw.tv.w[3], raw.tv.w[2], a); tw[3] = raw.tv.w[3] >> a;
         qw[0] = lz_alignbit(raw.qv.w[1], raw.qv.w[0], b); qw[1] = lz_alignbit(raw.qv.w[2], raw.qv.w[1], b); qw[2] = lz_alignbit(raw.qv.w[3], raw.qv.w[2], b); qw[3] = raw.qv.w[3] >> b;
     }
@@ -130,8 +151,7 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     u32 nd = 0;                                                 // groups NOT passed (dead is sticky)
     LZ_UNROLL_ALL
     for (int g = 0; g < LZ_LUT_WIN_G; g++) {
-        const int byte = RIGHT ? g : 14 - g;
-        const LzLutEntry e = lut[lz_byte_pair(wc[byte >> 2], xw[byte >> 2], byte & 3)];
+        const LzLutEntry e = lut[lz_byte_pair(wc[g >> 2], xw[g >> 2], g & 3)];
         dead = dead | (m < (s32)(e.ab & 0xFFFFu));
         if (LIMCHK) dead = dead | ((u32)g >= glim);
         const s32 bq = (s32)e.ab >> 16;
@@ -144,7 +164,7 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     u32 r = 0;
     if (np < (u32)LZ_LUT_WIN_G) { r = lim - 4u * np; if (r > 4u) r = 4u; }       // 4: the margin test failed inside the limit
     s32 best = run - m + X;
-    const u32 byte = (RIGHT ? np : 14u - np) & 15u, wsel = byte >> 2, bsh = 8u * (byte & 3u);
+    const u32 byte = np & 15u, wsel = byte >> 2, bsh = 8u * (byte & 3u);
     const u32 xsel = wsel == 0 ? xw[0] : wsel == 1 ? xw[1] : wsel == 2 ? xw[2] : xw[3];
     const u32 csel = wsel == 0 ? wc[0] : wsel == 1 ? wc[1] : wsel == 2 ? wc[2] : wc[3];
     const u32 sc = lut[(((csel >> bsh) & 0xFFu) << 8) | ((xsel >> bsh) & 0xFFu)].sc;
@@ -178,6 +198,16 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     else if (lim == st.room) st.alive = 0;                              // end of a sequence / the left stop
     else { st.alive = 1; st.room -= (u32)LZ_LUT_WIN_B; st.s = RIGHT ? st.s + (u32)LZ_LUT_WIN_B : st.s - (u32)LZ_LUT_WIN_B; }
 }
+// the first windows of both scans of a hit (do_l / do_r: which of them this lane runs).  (Stepping the two windows
+// side by side in one instruction stream -- two dependent chains per lane -- was measured and lost: 138 VGPRs,
+// three waves per SIMD instead of four, k_probe_part 120 -> 167 ms per step.)
+template <bool SPECIAL, bool LIMCHK>
+LZ_HD void lz_lut_window_pair(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& L, LzLutScan& R,
+                              const LzLutRaw<SPECIAL>& rawl, const LzLutRaw<SPECIAL>& rawr, bool do_l, bool do_r)
+{
+    if (do_l) lz_lut_window<false, SPECIAL, LIMCHK>(P, lut, diag, L, rawl);
+    if (do_r) lz_lut_window<true, SPECIAL, LIMCHK>(P, lut, diag, R, rawr);
+}
 // fetch + window
 template <bool RIGHT, bool SPECIAL>
 LZ_HD void lz_lut_step(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& st)
@@ -210,13 +240,12 @@ LZ_HD u32 lz_lut_summary(const LzLutScan& L, const LzLutScan& R, s32 min_score)
 }
 
 template <bool SPECIAL>
-LZ_HD u32 lz_lut_probe_hit(const LzLutParams& P, const LzLutEntry* lut_r, const LzLutEntry* lut_l,
-                           u32 tlen, u32 qlen, s32 min_score, u64 key)
+LZ_HD u32 lz_lut_probe_hit(const LzLutParams& P, const LzLutEntry* lut, u32 tlen, u32 qlen, s32 min_score, u64 key)
 {
     s32 diag; LzLutScan L, R;
     lz_lut_init(key, tlen, qlen, diag, L, R);
-    while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SPECIAL>(P, lut_l, diag, L);
-    while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SPECIAL>(P, lut_r, diag, R);
+    while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SPECIAL>(P, lut, diag, L);
+    while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SPECIAL>(P, lut, diag, R);
     return lz_lut_summary(L, R, min_score);
 }
 

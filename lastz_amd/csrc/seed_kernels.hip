@@ -470,11 +470,11 @@ void lz_phase_clocks_print()
 #define LZ_CLK(slot)
 void lz_phase_clocks_print() {}
 #endif
-#define LZ_PP_TPB    1024
+#define LZ_PP_TPB    512
 #define LZ_PP_WAVES  (LZ_PP_TPB / 64)
 #define LZ_PP_ROUNDS 4
 #define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile
-#define LZ_PP_QCAP   256                             // unfinished scans a tile can queue (beyond that the hit is left to phase B)
+#define LZ_PP_QCAP   96                              // unfinished scans a tile can queue (beyond that the hit is left to phase B)
 #define LZ_NBIN      256
 #define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // bits 8..15 of hashedDiag
 
@@ -563,25 +563,26 @@ __device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
     return pre + inc - v;
 }
 
-// One workgroup of 1024 lanes per tile of 4096 hits (a wave owns 256 consecutive hits, 64 at a time); the
-// kernel is a sequence of short rolled loops over those four rounds, what a hit needs from one loop to the next
-// travels through LDS (info[]), so that the heavy code -- the unrolled, branch-free window of lz_lut.hpp --
-// exists four times only (head and continuation, left and right) and the register budget stays at 4 waves / SIMD.
+// One workgroup of 512 lanes per tile of 2048 hits (a wave owns 256 consecutive hits, 64 at a time), two
+// workgroups per CU (78 KiB of LDS each: one 32 KiB table serves both scan directions), so that one workgroup's
+// barriers, queue drain and write-out overlap the other's scans.  The kernel is a sequence of short rolled loops
+// over the four rounds; what a hit needs from one loop to the next travels through LDS (info[]), so that the
+// heavy code -- the unrolled, branch-free window of lz_lut.hpp -- exists four times only (head and continuation,
+// left and right).
 struct LzPPTask { u32 s; s32 run, best; u32 room, used, nwin; s32 diag; u32 li_side; };
 #define LZ_PP_INFO(used, alive, best) (((used) & 0xFFu) | (((alive) & 3u) << 8) | ((u32)(best) << 16))
 struct LzPPShared {
     union {
-        LzLutEntry lut[2 * LZ_LUT_ENTRIES];                             // MODE 0/1: right table, left table (64 KiB)
+        LzLutEntry lut[LZ_LUT_ENTRIES];                                 // MODE 0/1: the look-up table (32 KiB)
         struct { s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64]; } bc;    // MODE 2: the byte-code scans' tables
     };
     u32 info[2 * LZ_PP_TILE];                        // per hit: left / right scan: bases consumed | alive << 8 | best << 16 (MODE 2: the summary)
-    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition
-    u8  sbin[LZ_PP_TILE];
+    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition (the partition rides in bits 55..62)
     u32 wcnt[LZ_PP_WAVES][LZ_NBIN];                  // per wave and partition: records / running offset inside the partition
     u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
     LzPPTask q[LZ_PP_QCAP]; u32 qn;
 };
-static_assert(LZ_PP_TILE == 4096 && sizeof(LzPPShared) <= 160 * 1024, "LDS budget of k_probe_part");
+static_assert(LZ_PP_TILE == LZ_PP_TILE_HOST && sizeof(LzPPShared) <= 80 * 1024, "LDS budget of k_probe_part: two workgroups per CU");
 
 template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
 __global__ void __launch_bounds__(LZ_PP_TPB)
@@ -591,12 +592,12 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
 {
     __shared__ LzPPShared sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (MODE < 2) { for (u32 k = tid; k < 2 * LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k]; }
+    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k]; }
     else {
         for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PP_TPB) sh.bc.tab[k] = score_tab_g[k];
         if (tid < 64) sh.bc.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
     }
-    const LzLutEntry* lut_r = sh.lut; const LzLutEntry* lut_l = sh.lut + LZ_LUT_ENTRIES;
+    const LzLutEntry* lut = sh.lut;
     constexpr bool SP = MODE == 1;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const u64 base = (u64)tile * LZ_PP_TILE;
@@ -641,8 +642,7 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
                 else { nrawl = rawl; nrawr = rawr; }
                 if (!valid) { L.alive = 0; R.alive = 0; }
                 const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
-                if (L.alive && !ql) lz_lut_window<false, SP, HLIM>(Q, lut_l, diag, L, rawl);
-                if (R.alive && !qr) lz_lut_window<true, SP, HLIM>(Q, lut_r, diag, R, rawr);
+                lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr);
                 if (L.alive == 1) {
                     const u32 slot = atomicAdd(&sh.qn, 1u);          // (a full queue leaves the scan "alive": the hit becomes SLOW)
                     if (slot < LZ_PP_QCAP) sh.q[slot] = { L.s, L.run, L.best, L.room, L.used, L.nwin, diag, (li << 1) | 0u };
@@ -669,8 +669,8 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
                 LzLutScan S; S.s = t.s; S.run = t.run; S.best = t.best; S.room = t.room; S.used = t.used; S.nwin = t.nwin; S.alive = 1;
                 while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) {
                     LzLutRaw<SP> raw;
-                    if (t.li_side & 1u) { lz_lut_fetch<true, SP>(Q, S.s, t.diag, raw);  lz_lut_window<true, SP, true>(Q, lut_r, t.diag, S, raw); }
-                    else                { lz_lut_fetch<false, SP>(Q, S.s, t.diag, raw); lz_lut_window<false, SP, true>(Q, lut_l, t.diag, S, raw); }
+                    if (t.li_side & 1u) { lz_lut_fetch<true, SP>(Q, S.s, t.diag, raw);  lz_lut_window<true, SP, true>(Q, lut, t.diag, S, raw); }
+                    else                { lz_lut_fetch<false, SP>(Q, S.s, t.diag, raw); lz_lut_window<false, SP, true>(Q, lut, t.diag, S, raw); }
                 }
                 sh.info[t.li_side] = LZ_PP_INFO(S.used, S.alive, S.best);
             }
@@ -717,15 +717,15 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
                     if (((il | ir) & 0x300u) || (s32)((il >> 16) + (ir >> 16)) >= P.min_score) summ |= LZ_SUMM_SLOW;
                 }
                 const u32 pos = sh.tstart[bin] + old + rank;
-                sh.stage[pos] = lz_hit_record(key, summ);
-                sh.sbin[pos] = (u8)bin;
+                sh.stage[pos] = lz_hit_record(key, summ) | ((u64)bin << 55);
             }
         }
         __syncthreads();
         LZ_CLK(7);
         for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
-            const u32 b = sh.sbin[k];
-            recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = sh.stage[k];
+            const u64 r = sh.stage[k];
+            const u32 b = (u32)(r >> 55) & 0xFFu;
+            recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = r & ~(0xFFull << 55);
         }
         __syncthreads();
         LZ_CLK(8);
@@ -738,7 +738,7 @@ int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParam
     if (n == 0) return 0;
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE);
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
-    const u32 grid = ntiles < (u32)cus ? ntiles : (u32)cus;     // one 1024-lane workgroup per CU (the tables fill most of its LDS)
+    const u32 grid = ntiles < 2u * (u32)cus ? ntiles : 2u * (u32)cus;   // two 512-lane workgroups per CU, each walking its share of the tiles
     c.timer.begin("k_probe_part", c.stream);
     if (mode == 0)      hipLaunchKernelGGL(k_probe_part<0>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
     else if (mode == 1) hipLaunchKernelGGL(k_probe_part<1>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);

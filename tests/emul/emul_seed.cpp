@@ -179,8 +179,8 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         std::vector<u64> rec(keys.size());
         for (size_t i = 0; i < keys.size(); i++) {
             u32 sm;
-            if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, P.tlen, P.qlen, P.min_score, keys[i]);
-            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), lut.data() + LZ_LUT_ENTRIES, P.tlen, P.qlen, P.min_score, keys[i]);
+            if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), P.tlen, P.qlen, P.min_score, keys[i]);
+            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), P.tlen, P.qlen, P.min_score, keys[i]);
             else                     sm = lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]);
             rec[i] = lz_hit_record(keys[i], sm);
         }

@@ -107,3 +107,19 @@ def test_two_mbp_pair_vs_oracle(gpu):
                 else:
                     s -= 400 + 30 * n; p1 += n
             assert s == a["s"]
+
+
+def test_identical_sequences_decline_case_insensitively(gpu):
+    """identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() bytes: a target paired with a
+    soft-masked copy of itself must take the reference's trivial-alignment path, i.e. be declined (> 0) here"""
+    sub, _ = H.scoring()
+    t, _ = seqio.synth_pair(50000, 100, seed=3)
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    segs = np.zeros(1, dtype=lzgpu.SEG_DTYPE); segs["pos1"] = 1000; segs["pos2"] = 1000; segs["length"] = 100; segs["s"] = 9000
+    for q in (t.copy(), t | 0x20, np.where(np.arange(len(t)) % 3 == 0, t | 0x20, t).astype(np.uint8)):
+        with pytest.raises(lzgpu.NotHandled) as e:
+            gpu.gapped_extend(sub, segs.copy(), q=q)
+        assert e.value.rc == 6
+    q = t.copy(); q[777] = ord("A") if q[777] != ord("A") else ord("C")     # one base apart: handled
+    al, _ = gpu.gapped_extend(sub, segs.copy(), q=q)
+    assert len(al) == 1
