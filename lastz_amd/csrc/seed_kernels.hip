@@ -842,7 +842,7 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 // lane's whole wave (lz_coop_extend_wave), one such record at a time.
 #define LZ_ST_TPB    1024
 #define LZ_ST_WAVES  (LZ_ST_TPB / 64)
-#define LZ_ST_TILE   8192
+#define LZ_ST_TILE   4096
 #define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
 #define LZ_ST_BATCH  4
 __global__ void __launch_bounds__(LZ_ST_TPB)
