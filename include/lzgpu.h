@@ -116,6 +116,14 @@ int lzgpu_table_commit(void);
  * run -- through files in <dir> (host staging; tests only).  `dir` must be a directory all ranks see and that
  * is empty at the start of the run. */
 int lzgpu_table_share(int rank, int world, const char* dir);
+/* On-disk form of the same payload (the role of the reference's capsule files, src/capsule.c, whose
+ * format is machine-dependent and not reused): a versioned little-endian file -- magic "LZGPUTAB", version, the
+ * geometry (lz_table_geom), the three buffers (target bytes, wstart, wpos) and an FNV-1a checksum -- so that a
+ * target's table is built once and loaded by later runs / other nodes.  lzgpu_table_load leaves the library in the
+ * state lzgpu_table_prepare would (the target bytes come from the file); LZGPU_ERR_ARG for a file that is not a
+ * table of this version, LZGPU_ERR_STATE for a damaged one. */
+int lzgpu_table_save(const char* path);
+int lzgpu_table_load(const char* path);
 /* device-to-device copy on the library's stream (lets a caller that received the broadcast in
  * its own allocation hand it over without knowing which HIP runtime object owns the stream). */
 int lzgpu_device_copy(void* dst_dev, const void* src_dev, uint64_t bytes);
@@ -175,6 +183,13 @@ typedef struct lz_gapped_args {
                                       as the reference does)                                      */
     uint32_t       n_anchors;
     int32_t        reduce;         /* 1: run reduce_to_points first                               */
+    /* partitioned sequences ("file[multi]", src/sequences.h:240-267): the positions of the NUL bytes
+       that bound the partitions, ascending -- partition i lies strictly between sep[i] and sep[i+1]
+       (n partitions: n+1 entries) -- or NULL.  An anchor's extension stays inside the partition
+       holding it (src/gapped_extend.c:1356-1372).  A pair holding two identical partitions is
+       declined (the reference adds trivial alignments for those, :1191-1290).                      */
+    const uint32_t* sep1;  uint32_t n_sep1;
+    const uint32_t* sep2;  uint32_t n_sep2;
 } lz_gapped_args;
 
 typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdbool.h>
+#include <unistd.h>
 #include "build_options.h"
 #include "utilities.h"
 #include "dna_utilities.h"
@@ -141,6 +142,21 @@ static int fast_seed (seed* hitSeed, lz_seed_desc* sd)
 	return true;
 	}
 
+/* the NUL separators bounding a [multi] sequence's partitions (src/sequences.h:240-267), NULL if it has none */
+static uint32_t* partition_separators (seq* s, uint32_t* n)
+	{
+	seqpartition* sp = &s->partition;
+	uint32_t*     v;
+	u32           i;
+
+	*n = 0;
+	if (sp->p == NULL) return NULL;
+	v = (uint32_t*) malloc_or_die ("lzgpu separators", ((size_t) sp->len + 1) * sizeof(uint32_t));
+	for (i=0 ; i<=sp->len ; i++) v[i] = sp->p[i].sepBefore;      /* (entry len: the final NUL) */
+	*n = sp->len + 1;
+	return v;
+	}
+
 /* ---- B1 ---- */
 
 postable* build_seed_position_table
@@ -150,6 +166,7 @@ postable* build_seed_position_table
 	postable*    pt;
 	unspos       e = (end == 0)? seq->len : end;
 	int          rc;
+	char         cachePath[1200];
 
 	/* the device holds ONE table: while the main target's table is live, any other table (the
 	   tweener's 7-mer tables on <=20 kbp windows, src/tweener.c:791) is built by the reference */
@@ -160,13 +177,27 @@ postable* build_seed_position_table
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
 
 	multi_init ();
+	cachePath[0] = 0;
+	if ((mgWorld == 1) && (getenv ("LZGPU_TABLE_CACHE") != NULL))   /* a table file per (target, seed, step, interval) */
+		{
+		u64 h = 1469598103934665603ull;  unspos i;  size_t k;
+		for (i=0 ; i<seq->len ; i++) { h ^= seq->v[i];  h *= 1099511628211ull; }
+		for (k=0 ; k<sizeof(sd) ; k++) { h ^= ((u8*) &sd)[k];  h *= 1099511628211ull; }
+		for (k=0 ; k<256 ; k++) { h ^= (u8) upperCharToBits[k];  h *= 1099511628211ull; }
+		snprintf (cachePath, sizeof(cachePath), "%s/%016llx.%u.%u.%u.%u.lztab", getenv ("LZGPU_TABLE_CACHE"),
+		          (unsigned long long) h, (unsigned) seq->len, (unsigned) start, (unsigned) e, (unsigned) step);
+		}
 	if ((mgWorld > 1) && (mgRank != 0)) rc = 0;                    /* the table comes from rank 0 */
+	else if ((cachePath[0] != 0) && (access (cachePath, R_OK) == 0) && (lzgpu_table_load (cachePath) == 0))
+		{ rc = 0;  note ("table", "loaded from the table cache");  cachePath[0] = 0; }
 	else rc = lzgpu_table_prepare (seq->v, seq->len, start, e, upperCharToBits, &sd, step);
 	if (rc < 0) suicidef ("lzgpu_table_prepare: %s", lzgpu_last_error());
 	if ((rc > 0) && (mgWorld > 1)) suicidef ("lzgpu_table_prepare declined (%d) in a multi-process run", rc);
 	if (rc > 0)
 		{ note ("table", "declined, reference path");  drop_device_table ();
 		  return ref_build_seed_position_table (seq, start, end, upperCharToBits, hitSeed, step); }
+	if ((cachePath[0] != 0) && (lzgpu_table_save (cachePath) != 0))
+		fprintf (stderr, "lzgpu: warning: %s\n", lzgpu_last_error());
 	if ((mgWorld > 1) || (getenv ("LZGPU_SHARE_FORCE") != NULL))
 		{
 		char dir[1024];                                            /* one rendezvous directory per table of the run */
@@ -257,6 +288,7 @@ alignel* gapped_extend
 	{
 	lz_gapped_args a;
 	lz_segment*    segs;
+	uint32_t*      sep1, *sep2;
 	lz_align*      al = NULL;
 	uint32_t*      ops = NULL;
 	uint64_t       n = 0, nops = 0, k;
@@ -275,7 +307,7 @@ alignel* gapped_extend
 
 	if ((devTargetV == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
 	 || (allBounds) || (!trimToPeak) || (scoreThresh.t != 'S') || (maxPairedBases != 0)
-	 || (seq1->partition.p != NULL) || (seq2->partition.p != NULL) || (seq2->choresFile != NULL)
+	 || ((gapped_extend_dbgAllowBatches) && (seq1->partition.p != NULL)) || (seq2->choresFile != NULL)
 	 || (tb == NULL) || (anchors == NULL) || (anchors->len == 0) || (scoring->gapExtend <= 0))
 		{ note ("gapped", "reference path");
 		  return ref_gapped_extend (seq1, rev1, seq2, rev2, inhibitTrivial, scoring, anchors, tb, allBounds, yDrop,
@@ -296,8 +328,11 @@ alignel* gapped_extend
 	a.ydrop = yDrop;  a.score_thresh = scoreThresh.s;  a.traceback_bytes = tb->size;
 	a.anchors = segs;  a.n_anchors = anchors->len;  a.reduce = 0;   /* reduce_to_points already ran, src/lastz.c:3401 */
 
+	sep1 = partition_separators (seq1, &a.n_sep1);  a.sep1 = sep1;
+	sep2 = partition_separators (seq2, &a.n_sep2);  a.sep2 = sep2;
+
 	rc = lzgpu_gapped_extend (&a, &al, &n, &ops, &nops);
-	free (segs);
+	free (segs);  free (sep1);  free (sep2);
 	if (rc < 0) suicidef ("lzgpu_gapped_extend: %s", lzgpu_last_error());
 	if (rc > 0)
 		{ note ("gapped", "declined, reference path");

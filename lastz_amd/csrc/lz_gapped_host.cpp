@@ -268,6 +268,27 @@ static bool align_touches(const LzHostSnapshot& S, const LzDpAlign& al, s64 r0, 
     return false;
 }
 
+// lookup_partition (src/sequences.c:6536-...): the limits [low, high) of the partition holding pos
+static bool partition_limits(const u32* sep, u32 n_sep, u32 pos, u32 len, u32& low, u32& high)
+{
+    if (!sep) { low = 0; high = len; return true; }
+    const u32* hi = std::upper_bound(sep, sep + n_sep, pos);          // first separator beyond pos
+    if (hi == sep || hi == sep + n_sep || hi[-1] == pos) return false;  // outside every partition / on a separator
+    low = hi[-1] + 1; high = hi[0];
+    return true;
+}
+
+static bool same_bases(const u8* a, const u8* b, u32 n)
+{
+    for (u32 i = 0; i < n; i++) {
+        u8 x = a[i], y = b[i];
+        if (x >= 'a' && x <= 'z') x -= 32;
+        if (y >= 'a' && y <= 'z') y -= 32;
+        if (x != y) return false;
+    }
+    return true;
+}
+
 int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,
                       std::vector<lz_align>& out, std::vector<u32>& out_ops, LzGappedStats& st)
 {
@@ -276,15 +297,19 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() of the bytes and, on a match, puts the
     // trivial self-alignment in front of every anchor (:1152-1189, not restated here): such a pair is declined.  The
     // test here folds the case of every ASCII letter -- a superset of dna_toupper's, so it can only decline more.
-    if (G.tlen == G.qlen) {
-        u32 i = 0;
-        for (; i < G.tlen; i++) {
-            u8 a = G.t[i], b = G.q[i];
-            if (a >= 'a' && a <= 'z') a -= 32;
-            if (b >= 'a' && b <= 'z') b -= 32;
-            if (a != b) break;
+    if (G.tlen == G.qlen && same_bases(G.t, G.q, G.tlen)) return LZGPU_NH_IDENTICAL;
+    // partitioned sequences: identical_partition_of_sequence / identical_partitioned_sequences (:1127-1147) make the
+    // reference add trivial alignments; any pair of (partition | whole sequence) with the same bases is declined
+    if (G.sep1 || G.sep2) {
+        for (u32 k = 0; k + 1 < G.n_sep1 || (!G.sep1 && k == 0); k++) {
+            const u32 lo1 = G.sep1 ? G.sep1[k] + 1 : 0, hi1 = G.sep1 ? G.sep1[k + 1] : G.tlen;
+            if (hi1 > G.tlen || lo1 > hi1) return LZGPU_ERR_ARG;
+            for (u32 m = 0; m + 1 < G.n_sep2 || (!G.sep2 && m == 0); m++) {
+                const u32 lo2 = G.sep2 ? G.sep2[m] + 1 : 0, hi2 = G.sep2 ? G.sep2[m + 1] : G.qlen;
+                if (hi2 > G.qlen || lo2 > hi2) return LZGPU_ERR_ARG;
+                if (hi1 - lo1 == hi2 - lo2 && hi1 > lo1 && same_bases(G.t + lo1, G.q + lo2, hi1 - lo1)) return LZGPU_NH_IDENTICAL;
+            }
         }
-        if (i == G.tlen) return LZGPU_NH_IDENTICAL;
     }
     if (G.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
 
@@ -365,12 +390,16 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             s32 below = -1, above = -1;
             for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < a1) { below = (s32)o; break; }
             for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > a1) { above = (s32)o; break; }
+            // the partition holding the anchor bounds its extension, :1356-1372 / ydrop_align :2515-2531
+            u32 low1, high1, low2, high2;
+            if (!partition_limits(G.sep1, G.n_sep1, a1, G.tlen, low1, high1) || !partition_limits(G.sep2, G.n_sep2, a2, G.qlen, low2, high2)
+                || a1 + 1 > high1 || a2 + 1 > high2) return LZGPU_ERR_STATE;
             LzDpJob L; memset(&L, 0, sizeof(L));
-            L.anchor1 = a1; L.anchor2 = a2; L.reversed = 1; L.M = a1 + 1; L.N = a2 + 1;
+            L.anchor1 = a1; L.anchor2 = a2; L.reversed = 1; L.M = a1 + 1 - low1; L.N = a2 + 1 - low2;
             L.left_align = nb.la; L.left_seg = nb.ls; L.right_align = nb.ra; L.right_seg = nb.rs;
             L.list_start = below;
             LzDpJob R = L;
-            R.reversed = 0; R.M = G.tlen - (a1 + 1); R.N = G.qlen - (a2 + 1); R.list_start = above;
+            R.reversed = 0; R.M = high1 - (a1 + 1); R.N = high2 - (a2 + 1); R.list_start = above;
             jobs.push_back(L); jobs.push_back(R);
             Cached cr; cr.a1 = a1; cr.a2 = a2; cr.nb = nb; cr.n_snap = n_snap;
             cache.emplace(j, std::move(cr));

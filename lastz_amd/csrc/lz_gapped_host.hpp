@@ -35,6 +35,8 @@ struct LzGappedParams {
     const s32* sub;                        // [256][256] unmasked scoring
     s32 gap_open, gap_extend, ydrop, score_thresh;
     u32 window;                            // max anchors speculated per round
+    const u32* sep1 = nullptr; u32 n_sep1 = 0;   // partition separators (lz_gapped_args), or none
+    const u32* sep2 = nullptr; u32 n_sep2 = 0;
 };
 
 struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };

@@ -110,3 +110,74 @@ extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
     if (rank != 0 && (rc = lzgpu_table_commit())) return rc;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// lzgpu_table_save / lzgpu_table_load: the same payload as a versioned file (the role of the reference's capsule
+// files, src/capsule.c:44-..., in this library's own layout)
+namespace {
+struct TabFileHead { char magic[8]; uint32_t version, endian, geom_bytes, pad; uint64_t bytes[3]; };
+const char kMagic[8] = { 'L', 'Z', 'G', 'P', 'U', 'T', 'A', 'B' };
+uint64_t fnv_more(const void* p, size_t n, uint64_t h) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+}
+
+extern "C" int lzgpu_table_save(const char* path)
+{
+    LzCtx& c = lz_ctx();
+    if (!path) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_save: null path");
+    lz_table_geom g; int rc;
+    if ((rc = lzgpu_table_geom(&g))) return rc;
+    void* ptr[3]; uint64_t bytes[3];
+    if ((rc = lzgpu_table_buffers(ptr, bytes))) return rc;
+    TabFileHead h; memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kMagic, 8); h.version = 1; h.endian = 0x01020304u; h.geom_bytes = (uint32_t)sizeof(g);
+    for (int k = 0; k < 3; k++) h.bytes[k] = bytes[k];
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_save: cannot create %s", tmp.c_str());
+    uint64_t sum = 1469598103934665603ull;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&g, sizeof(g), 1, f) == 1;
+    sum = fnv_more(&h, sizeof(h), sum); sum = fnv_more(&g, sizeof(g), sum);
+    std::vector<char> host;
+    for (int k = 0; k < 3 && ok; k++) {
+        host.resize(bytes[k] ? bytes[k] : 1);
+        if (bytes[k] && hipMemcpy(host.data(), ptr[k], bytes[k], hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = bytes[k] == 0 || fwrite(host.data(), 1, bytes[k], f) == bytes[k];
+        sum = fnv_more(host.data(), bytes[k], sum);
+    }
+    ok = ok && fwrite(&sum, 8, 1, f) == 1;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { unlink(tmp.c_str()); return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_save: writing %s failed", path); }
+    (void)c;
+    return 0;
+}
+
+extern "C" int lzgpu_table_load(const char* path)
+{
+    LzCtx& c = lz_ctx();
+    if (!path) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_load: null path");
+    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    FILE* f = fopen(path, "rb");
+    if (!f) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_load: cannot open %s", path);
+    TabFileHead h; lz_table_geom g;
+    uint64_t sum = 1469598103934665603ull;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kMagic, 8) != 0 || h.version != 1 || h.endian != 0x01020304u
+        || h.geom_bytes != sizeof(g) || fread(&g, sizeof(g), 1, f) != 1) { fclose(f); return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_load: %s is not a version-1 table file", path); }
+    sum = fnv_more(&h, sizeof(h), sum); sum = fnv_more(&g, sizeof(g), sum);
+    int rc = lzgpu_table_adopt(&g);
+    if (rc) { fclose(f); return rc; }
+    void* ptr[3]; uint64_t bytes[3];
+    if ((rc = lzgpu_table_buffers(ptr, bytes))) { fclose(f); return rc; }
+    std::vector<char> host;
+    for (int k = 0; k < 3; k++) {
+        if (bytes[k] != h.bytes[k]) { fclose(f); return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_load: %s: buffer %d has %llu bytes, its geometry says %llu", path, k, (unsigned long long)h.bytes[k], (unsigned long long)bytes[k]); }
+        host.resize(bytes[k] ? bytes[k] : 1);
+        if (bytes[k] && fread(host.data(), 1, bytes[k], f) != bytes[k]) { fclose(f); return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_load: %s is truncated", path); }
+        sum = fnv_more(host.data(), bytes[k], sum);
+        if (bytes[k]) LZ_HIP(hipMemcpy(ptr[k], host.data(), bytes[k], hipMemcpyHostToDevice));
+    }
+    uint64_t want = 0;
+    const bool ok = fread(&want, 8, 1, f) == 1 && want == sum;
+    fclose(f);
+    if (!ok) { c.have_table = false; return lz_fail(LZGPU_ERR_STATE, "lzgpu_table_load: %s fails its checksum", path); }
+    return lzgpu_table_commit();
+}

@@ -38,7 +38,8 @@ class GappedArgs(C.Structure):
     _fields_ = [("query", C.c_void_p), ("qlen", C.c_uint32), ("query_slot", C.c_int32),
                 ("sub", C.c_void_p), ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
                 ("ydrop", C.c_int32), ("score_thresh", C.c_int32), ("traceback_bytes", C.c_uint32),
-                ("anchors", C.c_void_p), ("n_anchors", C.c_uint32), ("reduce", C.c_int32)]
+                ("anchors", C.c_void_p), ("n_anchors", C.c_uint32), ("reduce", C.c_int32),
+                ("sep1", C.c_void_p), ("n_sep1", C.c_uint32), ("sep2", C.c_void_p), ("n_sep2", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -55,7 +56,7 @@ ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end
 # every symbol include/lzgpu.h declares (tests check that the library exports all of them)
 EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdown", "lzgpu_free",
            "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
-           "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_device_copy",
+           "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_table_save", "lzgpu_table_load", "lzgpu_device_copy",
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window",
@@ -213,6 +214,12 @@ class Lib:
     def set_bucket_owner(self, n_owners, owner):
         self._check(self._f("set_bucket_owner")(C.c_uint32(n_owners), C.c_uint32(owner)), "lzgpu_set_bucket_owner")
 
+    def table_save(self, path):
+        self._check(self.L.lzgpu_table_save(str(path).encode()), "lzgpu_table_save")
+
+    def table_load(self, path):
+        self._check(self.L.lzgpu_table_load(str(path).encode()), "lzgpu_table_load")
+
     def last_scan_mode(self):
         return int(self.L.lzgpu_last_scan_mode())
 
@@ -231,8 +238,13 @@ class Lib:
 
     # ---- B3
     def gapped_extend(self, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400,
-                      score_thresh=3000, traceback_bytes=0, reduce=True):
+                      score_thresh=3000, traceback_bytes=0, reduce=True, sep1=None, sep2=None):
+        """sep1 / sep2: positions of the NUL bytes bounding the partitions of a [multi] target / query"""
         a = GappedArgs()
+        if sep1 is not None:
+            sep1 = np.ascontiguousarray(sep1, dtype=np.uint32); a.sep1, a.n_sep1 = sep1.ctypes.data, len(sep1)
+        if sep2 is not None:
+            sep2 = np.ascontiguousarray(sep2, dtype=np.uint32); a.sep2, a.n_sep2 = sep2.ctypes.data, len(sep2)
         sub = np.ascontiguousarray(sub, dtype=np.int32)
         anchors = np.ascontiguousarray(anchors.copy(), dtype=SEG_DTYPE)
         if q is not None:

@@ -72,6 +72,40 @@ def test_same_bytes_as_pristine_binary(sandbox, fmt):
 
 
 @needs_bins
+def test_table_cache_directory(sandbox, tmp_path):
+    """LZGPU_TABLE_CACHE: the first run writes the target's table file, the second loads it; same bytes out."""
+    t, q = seqio.synth_pair(400_000, 300_000, seed=43)
+    seqio.write_fasta(sandbox / "tc.fa", [("target", t)]); seqio.write_fasta(sandbox / "qc.fa", [("q", q)])
+    cache = tmp_path / "cache"; os.makedirs(cache)
+    env = {"LZGPU_VERBOSE": "1", "LZGPU_TABLE_CACHE": str(cache)}
+    a, ea = run(GPU_BIN, ["tc.fa", "qc.fa", "--format=maf"], sandbox, env)
+    assert "[lzgpu] table: built on the GPU" in ea and len(os.listdir(cache)) == 1
+    b, eb = run(GPU_BIN, ["tc.fa", "qc.fa", "--format=maf"], sandbox, env)
+    assert "[lzgpu] table: loaded from the table cache" in eb and len(os.listdir(cache)) == 1
+    c, ec = run(GPU_BIN, ["tc.fa", "qc.fa", "--format=maf", "--step=2"], sandbox, env)     # another table: another file
+    assert "loaded from the table cache" not in ec and len(os.listdir(cache)) == 2
+    ref, _ = run(REF_BIN, ["tc.fa", "qc.fa", "--format=maf"], sandbox)
+    strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+    assert strip(a) == strip(b) == strip(ref) and len(a) > 1000
+
+
+@needs_bins
+@pytest.mark.parametrize("qmulti", [False, True], ids=["target-multi", "both-multi"])
+def test_partitioned_sequences_gapped_on_gpu(sandbox, qmulti):
+    """file[multi] (whole assemblies as one target): the gapped stage keeps every extension inside the
+    partition holding its anchor (src/gapped_extend.c:1356-1372); same bytes as the pristine binary."""
+    t, q = seqio.synth_pair(900_000, 800_000, seed=47)
+    seqio.write_fasta(sandbox / "tm.fa", [("c1", t[:250_000]), ("c2", t[250_000:610_000]), ("c3", t[610_000:])])
+    seqio.write_fasta(sandbox / "qm.fa", [("q1", q[:300_000]), ("q2", q[300_000:])])
+    args = ["tm.fa[multi]", "qm.fa" + ("[multi]" if qmulti else ""), "--format=maf", "--ydrop=9430"]
+    a, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+    b, _ = run(REF_BIN, args, sandbox)
+    assert "[lzgpu] gapped: done on the GPU" in err and "[lzgpu] search: done on the GPU" in err, err[-1500:]
+    strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+    assert strip(a) == strip(b) and len(a) > 5000
+
+
+@needs_bins
 def test_gapped_stage_alone_from_saved_segments(sandbox):
     """src/Makefile:384-400: HSPs saved with --format=segments, gapped stage run from --segments=<file>
     (B3 in isolation) must give base_test.default.lav"""

@@ -52,6 +52,39 @@ def test_position_table_matches_reference_layout(gpu, pattern, wt, step, start, 
     assert (prev == np.ctypeslib.as_array(pt.prev, shape=(pt.prev_entries,))).all()
 
 
+def test_table_file_round_trip(gpu, tmp_path):
+    """SURVEY 8f N4 (the capsule's role): a table saved to this library's versioned file, loaded into a fresh library
+    state, gives the same table and the same HSPs; damaged and foreign files are refused."""
+    t, q = seqio.synth_pair(300_000, 120_000, seed=77)
+    _, masked = H.scoring()
+    tab = _prep(gpu, t, "111101101111", 1, 2, 500, 290_000)
+    f = str(tmp_path / "t.lztab")
+    gpu.table_save(f)
+    gpu.shutdown(); gpu.init()
+    gpu.table_load(f)
+    pt = tab.pt.contents
+    assert gpu.table_num_words() == pt.words_in_table
+    last, prev = gpu.table_export(pt.prev_entries)
+    assert (last == np.ctypeslib.as_array(pt.last, shape=(pt.word_entries,))).all()
+    assert (prev == np.ctypeslib.as_array(pt.prev, shape=(pt.prev_entries,))).all()
+    for strand in (0, 1):
+        qq = q if strand == 0 else seqio.revcomp(q)
+        _same_hsps(gpu, tab, qq, masked, xdrop=910, hsp_threshold=3000)
+    raw = bytearray(open(f, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(f, "wb").write(bytes(raw))
+    with pytest.raises(lzgpu.LzGpuError, match="checksum"):
+        gpu.table_load(f)
+    open(f, "wb").write(bytes(raw[:len(raw) // 3]))
+    with pytest.raises(lzgpu.LzGpuError, match="truncated"):
+        gpu.table_load(f)
+    open(f, "wb").write(b"not a table" * 20)
+    with pytest.raises(lzgpu.LzGpuError, match="not a version-1 table"):
+        gpu.table_load(f)
+    gpu.table_prepare(t, gpu.seed(H.DEFAULT_SEED, 1), CTB)       # and the library recovers
+    assert gpu.table_num_words() > 0
+
+
 def test_reference_goldens_hits_and_hsps(gpu):
     """base_test.hits.lav (raw hits, plain processor) and base_test.hsp.lav (X-drop HSPs)"""
     tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
