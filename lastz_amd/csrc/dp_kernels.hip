@@ -62,7 +62,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 
     // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: a DPP scan inside each wave, per-wave
     // partials through LDS, then every lane folds in the partials of the waves below it.
-    __device__ __forceinline__ s32 scan_gap(LzDpShared& sh, s32 x0)
+    __device__ __forceinline__ s32 scan_gap(LzDpSharedBase& sh, s32 x0)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         const LzDpGap x = { regs.A, regs.K, regs.cut };
@@ -78,7 +78,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
         return xend;                                            // (wg[] is rewritten a row later, barriers in between)
     }
-    __device__ __forceinline__ void scan_cand(LzDpShared& sh, s32 b0)
+    __device__ __forceinline__ void scan_cand(LzDpSharedBase& sh, s32 b0)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         const s32 x = regs.cand;
@@ -91,7 +91,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         for (int j = 0; j < w; j++) if (sh.wc[j] > pre) pre = sh.wc[j];
         regs.run_in = ex > pre ? ex : pre;
     }
-    __device__ __forceinline__ void reduce_row(LzDpShared& sh)
+    __device__ __forceinline__ void reduce_row(LzDpSharedBase& sh)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
         const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
@@ -106,7 +106,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
         __syncthreads();
     }
-    __device__ __forceinline__ void row_result(const LzDpShared& sh, u32& first, u32& last, s32& cmax, u32& ccol)   // lane 0
+    __device__ __forceinline__ void row_result(const LzDpSharedBase& sh, u32& first, u32& last, s32& cmax, u32& ccol)   // lane 0
     {
         u32 f = 0xFFFFFFFFu, l = 0xFFFFFFFFu, cc = 0; s32 cm = LZ_DP_NEGINF - (1 << 24);
 #pragma unroll
@@ -133,6 +133,23 @@ k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u3
     lz_dp_run(x, sh, S, P, J, tab, &res[j]);
 }
 
+// The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
+__global__ void __launch_bounds__(LZ_DP_LANES)
+k_ydrop_wide(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
+             const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u8* __restrict__ rings)
+{
+    __shared__ LzDpSharedWide sh;
+    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
+    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
+    if (threadIdx.x == 0) sh.bind(rings + (size_t)blockIdx.x * LzDpRingHbm::SLOT_BYTES);
+    __syncthreads();
+    const u32 j = job_ids[blockIdx.x];
+    GpuPhases x;
+    x.lead_wave = (int)(blockIdx.x & (LZ_DP_WAVES - 1));
+    const LzDpJob J = jobs[j];
+    lz_dp_run(x, sh, S, P, J, tab, &res[j]);
+}
+
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
 __global__ void __launch_bounds__(256)
 k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ res, const u32* __restrict__ ops_arena,
@@ -146,12 +163,12 @@ k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ re
 }
 
 struct DpBufs {
-    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act;
+    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings;
 };
 static DpBufs g_dp;
 void lz_dp_release_statics()
 {
-    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act };
+    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings };
     for (DevBuf* x : b) x->release();
 }
 
@@ -162,8 +179,9 @@ struct HipDpExec : LzDpExecutor {
     u64 dp_launch_cells = 0;
     explicit HipDpExec(LzCtx& ctx) : c(ctx) {}
 
+    u64 wide_runs = 0;
     int launch(const LzDpSnapshot& S, std::vector<LzDpJob>& jobs, const std::vector<u32>& ids, u32 slot,
-               std::vector<LzDpResult>& res)
+               std::vector<LzDpResult>& res, bool wide = false)
     {
         // slots: tb = slot bytes, rows = slot/16 entries, ops = slot/32 entries (all per DP)
         const u64 n = ids.size();
@@ -187,9 +205,17 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.stream));
         P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
         P.act_arena = g_dp.act.as<LzDpActive>();
-        c.timer.begin("k_ydrop", c.stream);
-        hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
-                           S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
+        if (wide) {
+            if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
+            wide_runs += n;
+            c.timer.begin("k_ydrop_wide", c.stream);
+            hipLaunchKernelGGL(k_ydrop_wide, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+                               S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
+        } else {
+            c.timer.begin("k_ydrop", c.stream);
+            hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+                               S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
+        }
         c.timer.end(c.stream);
         LZ_HIP(hipGetLastError());
         // results of this launch
@@ -260,29 +286,36 @@ struct HipDpExec : LzDpExecutor {
         S.obi = g_dp.obi.as<s32>(); S.oed = g_dp.oed.as<s32>(); S.n_aligns = (s32)na;
 
         // ---- first try: every job in a small slot; then the (rare) overflows in growing slots
-        std::vector<u32> ids(jobs.size());
+        std::vector<u32> ids(jobs.size()), wide_ids;
         for (u32 k = 0; k < jobs.size(); k++) ids[k] = k;
         u32 slot = slot_tb;
-        while (!ids.empty()) {
+        while (!ids.empty() || !wide_ids.empty()) {
             // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch
             const u64 per = (u64)slot + (u64)(slot / 16 + 64) * 4 + (u64)(slot / 32 + 64) * 4;
             u64 max_jobs = (48ull << 30) / per; if (max_jobs < 1) max_jobs = 1;
-            std::vector<u32> retry;
-            for (size_t base = 0; base < ids.size(); base += max_jobs) {
-                std::vector<u32> part(ids.begin() + base, ids.begin() + std::min<size_t>(ids.size(), base + max_jobs));
-                if ((rc = launch(S, jobs, part, slot, res))) return rc;
-                std::vector<u32> good;
-                for (u32 id : part) {
-                    const u32 stt = res[id].status;
-                    if (stt == LZ_DP_OK) good.push_back(id);
-                    else if (stt == LZ_DP_TB_SLOT || stt == LZ_DP_ROW_SLOT || stt == LZ_DP_OPS_SLOT) retry.push_back(id);
-                    else return LZGPU_NH_UNSUPPORTED;              // band wider than the LDS ring / too many active segments
+            std::vector<u32> retry, retry_wide;
+            // the LDS-ring kernel first; what it finds too wide joins the HBM-ring launch of the same pass
+            for (int pass = 0; pass < 2; pass++) {
+                const bool wide = pass == 1;
+                const std::vector<u32>& todo = wide ? wide_ids : ids;
+                const u64 cap = wide ? std::min<u64>(max_jobs, 2048) : max_jobs;      // (2048 rings = 1.8 GiB)
+                for (size_t base = 0; base < todo.size(); base += cap) {
+                    std::vector<u32> part(todo.begin() + base, todo.begin() + std::min<size_t>(todo.size(), base + cap));
+                    if ((rc = launch(S, jobs, part, slot, res, wide))) return rc;
+                    std::vector<u32> good;
+                    for (u32 id : part) {
+                        const u32 stt = res[id].status;
+                        if (stt == LZ_DP_OK) good.push_back(id);
+                        else if (stt == LZ_DP_TB_SLOT || stt == LZ_DP_ROW_SLOT || stt == LZ_DP_OPS_SLOT) (wide ? retry_wide : retry).push_back(id);
+                        else if (stt == LZ_DP_TOO_WIDE && !wide) wide_ids.push_back(id);
+                        else return LZGPU_NH_UNSUPPORTED;          // band wider than the HBM ring / too many active segments
+                    }
+                    if ((rc = fetch_ops(jobs, good, res, ops))) return rc;
                 }
-                if ((rc = fetch_ops(jobs, good, res, ops))) return rc;
             }
             const u64 max_slot = std::max<u64>(P.tb_len, 1u << 20) * 2;
-            if (!retry.empty() && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
-            ids.swap(retry);
+            if ((!retry.empty() || !retry_wide.empty()) && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
+            ids.swap(retry); wide_ids.swap(retry_wide);
             slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
         }
         return 0;

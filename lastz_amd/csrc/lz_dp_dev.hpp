@@ -34,6 +34,7 @@
 #define LZ_DP_LANES   256             // lanes (threads) per one-sided DP: 4 waves of one workgroup
 #define LZ_DP_WAVES   (LZ_DP_LANES / 64)
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
+#define LZ_DP_WIDEW   65536           // ... of the wide variant, whose ring lives in HBM (bands the LDS ring cannot hold)
 #define LZ_DP_TBWIN   64              // traceback look-ahead window (links along one diagonal)
 #define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -92,11 +93,23 @@ struct LzDpParams {                     // per batch
 struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
 struct LzDpActive { s32 align, seg; u32 x, last_row; s32 type; s32 filter; };
 
-struct LzDpShared {
-    s32 cc[LZ_DP_MAXW], dd[LZ_DP_MAXW];   // C[row][col], D[row+1][col]: ring, index col & (MAXW-1)
-    u32 mk[LZ_DP_MAXW];                   // mask stamps (= row number), :3706
-    u8  lk[LZ_DP_MAXW];                   // traceback link of the current row
-    u8  bb[LZ_DP_MAXW];                   // B (query) score classes of the band's columns, ring by column
+// The sweep row is a ring indexed by column & (RING-1).  Two homes for it: arrays in the DP's LDS block (the
+// normal kernel), or a slot in HBM behind pointers (k_ydrop_wide: the rare bands wider than the LDS ring --
+// small gap-extension penalties, huge y-drops; the same code, flat loads instead of ds loads).
+template <u32 W> struct LzDpRingLds {
+    static constexpr u32 RING = W;
+    s32 cc[W], dd[W];                     // C[row][col], D[row+1][col]
+    u32 mk[W];                            // mask stamps (= row number), :3706
+    u8  lk[W];                            // traceback link of the current row
+    u8  bb[W];                            // B (query) score classes of the band's columns
+};
+struct LzDpRingHbm {
+    static constexpr u32 RING = LZ_DP_WIDEW;
+    s32 *cc, *dd; u32* mk; u8 *lk, *bb;
+    static constexpr size_t SLOT_BYTES = (size_t)LZ_DP_WIDEW * 14;
+    LZ_HD void bind(u8* slot) { cc = (s32*)slot; dd = cc + LZ_DP_WIDEW; mk = (u32*)(dd + LZ_DP_WIDEW); lk = (u8*)(mk + LZ_DP_WIDEW); bb = lk + LZ_DP_WIDEW; }
+};
+struct LzDpSharedBase {
     u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
     // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
     LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
@@ -109,6 +122,9 @@ struct LzDpShared {
     u8  tb_win[64];
     LzDpActive act[LZ_DP_ACT_LDS];        // the first active segments; the rest live in the job's HBM slot
 };
+template <class Ring> struct LzDpSharedT : LzDpSharedBase, Ring {};
+typedef LzDpSharedT<LzDpRingLds<LZ_DP_MAXW>> LzDpShared;
+typedef LzDpSharedT<LzDpRingHbm> LzDpSharedWide;
 
 // Sweep state of one DP.  Only lane 0 reads and writes it, so it lives in that lane's registers:
 // the row-end / row-set-up step is a serial piece of code that every other lane waits for, and with
@@ -174,7 +190,7 @@ LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
 #define LZ_PHASE_CLOCK() ((u64)0)
 #endif
 #define LZ_SDIFF(a, b) (((s32)(a)) - ((s32)(b)))
-#define LZ_RING(c) ((c) & (LZ_DP_MAXW - 1))
+#define LZ_RING(c) ((c) & (SH::RING - 1))
 
 // next_sweep_seg / prev_sweep_seg, src/gapped_extend.c:4754-4850
 LZ_HD s32 lz_dp_next_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, s32& al, u32 row, u32 a1, u32 a2)
@@ -250,8 +266,8 @@ LZ_HD void lz_dp_update_lr(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJo
 
 // build_active_seg, src/gapped_extend.c:4992-5035: only cells inside [LY,RY] are stamped (that
 // also keeps the ring free of aliases: RY - LY < MAXW)
-LZ_HD void lz_dp_stamp(LzDpShared& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = row; }
-LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive& act)
+template <class SH> LZ_HD void lz_dp_stamp(SH& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = row; }
+template <class SH> LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, SH& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive& act)
 {
     const LzDpSeg& sg = S.segs[act.seg];
     act.type = sg.type;
@@ -276,11 +292,11 @@ LZ_HD void lz_dp_peek_list(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJo
     c.next_act_row = x.uni(J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1));
 }
 
-LZ_HD LzDpActive& lz_dp_act(LzDpShared& sh, LzDpActive* spill, u32 k) { return k < LZ_DP_ACT_LDS ? sh.act[k] : spill[k - LZ_DP_ACT_LDS]; }
+LZ_HD LzDpActive& lz_dp_act(LzDpSharedBase& sh, LzDpActive* spill, u32 k) { return k < LZ_DP_ACT_LDS ? sh.act[k] : spill[k - LZ_DP_ACT_LDS]; }
 
 // update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
-template <class X>
-LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive* spill)
+template <class X, class SH>
+LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, SH& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive* spill)
 {
     const u32 row = c.row;
     for (u32 k = 0; k < c.n_act; k++) {
@@ -320,8 +336,8 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, LzDpShared& sh, LzDp
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class X>
-LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
+template <class X, class SH>
+LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
 {
     const s32 gapE = P.gap_e, gapOE = P.gap_oe, Y = P.ydrop;
@@ -361,7 +377,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
         // row 0: C[0][0]=0, then insertions while the PREVIOUS column's C is >= -yDrop (note 13)
         u32 n0 = 1; s32 prevc = 0, c = -gapOE;
         while (n0 <= N && prevc >= -Y) { prevc = c; c -= gapE; n0++; }
-        if (n0 + LZ_DP_LANES + 72 > LZ_DP_MAXW) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; }
+        if (n0 + LZ_DP_LANES + 72 > SH::RING) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; }
         if (n0 > J.tb_cap || J.row_cap < 2) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; }
         ct.LY = 0; ct.RY = n0; ct.tb_used = n0; ct.cells = n0;
         if (!ct.done) trow[0] = 0;
@@ -373,7 +389,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
             // the mask stamps are row numbers: a previous job's stamps must not survive in the LDS block
-            for (u32 k = (u32)lane; k < LZ_DP_MAXW; k += LZ_DP_LANES) sh.mk[k] = 0;
+            for (u32 k = (u32)lane; k < SH::RING; k += LZ_DP_LANES) sh.mk[k] = 0;
             for (u32 col = 1 + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES) sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
             sh.aa[lane] = (1 + (u32)lane <= M) ? (u8)(lz_dp_a(P, J, 1 + (u32)lane) & 31u) : 0;      // rows 1..64
             for (u32 col = (u32)lane; col < sh.ry_iter; col += LZ_DP_LANES) {
@@ -452,7 +468,7 @@ LZ_HD void lz_dp_run(X& x, LzDpShared& sh, const LzDpSnapshot& S, const LzDpPara
             const s32 tb_needed = (s32)width + P.ydrop_tail;
             if ((s64)ct.tb_used + tb_needed >= (s64)P.tb_len) { ct.truncated = 1; ct.done = 1; ct.row--; return; }   // :3640-3661
             if ((u64)ct.tb_used + (u64)tb_needed > (u64)J.tb_cap) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; return; }
-            if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > LZ_DP_MAXW) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; return; }
+            if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > SH::RING) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; return; }
             if (ct.row + 1 >= J.row_cap) { ct.status = LZ_DP_ROW_SLOT; ct.done = 1; return; }
             trow[ct.row] = sh.trow_cur = ct.tb_used - ct.LY;    // tbRow[row], :3662 (u32 wrap intended)
             sh.ry_iter = ct.RY;

@@ -17,14 +17,14 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
     int lead_lane() const { return 0; }
     s32 uni(s32 v) { return v; }
     u32 uni(u32 v) { return v; }
-    void row_result(const LzDpShared& sh, u32& first, u32& last, s32& cmax, u32& ccol) { first = sh.r_first; last = sh.r_last; cmax = sh.r_cmax; ccol = sh.r_ccol; }
-    s32 scan_gap(LzDpShared&, s32 x0) {
+    void row_result(const LzDpSharedBase& sh, u32& first, u32& last, s32& cmax, u32& ccol) { first = sh.r_first; last = sh.r_last; cmax = sh.r_cmax; ccol = sh.r_ccol; }
+    s32 scan_gap(LzDpSharedBase&, s32 x0) {
         s32 x = x0;
         for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].i_in = x; LzDpGap f = { lanes[l].A, lanes[l].K, lanes[l].cut }; x = lz_dp_gap_apply(f, x); }
         return x;
     }
-    void scan_cand(LzDpShared&, s32 b0) { s32 rb = b0; for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].run_in = rb; if (lanes[l].cand > rb) rb = lanes[l].cand; } }
-    void reduce_row(LzDpShared& sh) {
+    void scan_cand(LzDpSharedBase&, s32 b0) { s32 rb = b0; for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].run_in = rb; if (lanes[l].cand > rb) rb = lanes[l].cand; } }
+    void reduce_row(LzDpSharedBase& sh) {
         u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu, ccol = 0; s32 cmax = LZ_DP_NEGINF - (1 << 24);
         for (int l = 0; l < LZ_DP_LANES; l++) {
             if (lanes[l].first != 0xFFFFFFFFu) { if (first == 0xFFFFFFFFu) first = lanes[l].first; last = lanes[l].last; }
@@ -39,7 +39,7 @@ struct EmulExec : LzDpExecutor {
     u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
     s32 gap_e, gap_oe, ydrop; u32 tb_len;
     u32 tb_slot;                        // first-try slot size (tests shrink it to exercise the retry)
-    u64 retries = 0;
+    u64 retries = 0, wide_runs = 0;
     int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
             std::vector<std::vector<u32>>& ops) override
     {
@@ -58,6 +58,14 @@ struct EmulExec : LzDpExecutor {
                 J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size(); J.act_off = 0;
                 CpuPhases x;
                 lz_dp_run(x, sh, S, P, J, tab, &res[k]);
+                if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
+                    static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
+                    static LzDpSharedWide shw;
+                    shw.bind(ring.data());
+                    CpuPhases xw;
+                    lz_dp_run(xw, shw, S, P, J, tab, &res[k]);
+                    wide_runs++;
+                }
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
                     if (slot >= tb_len) return LZGPU_ERR_STATE;
                     slot = slot * 4 < tb_len ? slot * 4 : tb_len; retries++;
@@ -78,9 +86,9 @@ static void dp_codes(const u8* seq, u32 len, const u8 cls[256], std::vector<u8>&
     for (u32 i = 0; i < len; i++) out[LZ_SEQ_PAD + i] = cls[seq[i]] & 31;
 }
 
-static LzGappedStats g_stats; static u64 g_retries;
+static LzGappedStats g_stats; static u64 g_retries, g_wide;
 extern "C" void emul_gapped_stats(u64* out) { out[0] = g_stats.anchors; out[1] = g_stats.anchors_extended; out[2] = g_stats.dp_runs;
-    out[3] = g_stats.dp_cells; out[4] = g_stats.rounds; out[5] = g_stats.reruns; out[6] = g_retries; }
+    out[3] = g_stats.dp_cells; out[4] = g_stats.rounds; out[5] = g_stats.reruns; out[6] = g_retries; out[7] = g_wide; }
 
 extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, const s32* sub,
                                   s32 gap_open, s32 gap_extend, s32 ydrop, s32 score_thresh, u32 tb_len,
@@ -98,7 +106,7 @@ extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, 
     if (reduce) lzh_reduce_to_points(t, q, sub, anchors, n_anchors);
     std::vector<lz_align> al; std::vector<u32> op;
     rc = lzh_gapped_extend(G, ex, anchors, n_anchors, al, op, g_stats);
-    g_retries = ex.retries;
+    g_retries = ex.retries; g_wide = ex.wide_runs;
     if (rc) return rc;
     *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
     *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);

@@ -27,11 +27,11 @@ def L():
     return lib
 
 
-def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3000, tb_len=0):
+def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3000, tb_len=0, gap_open=400, gap_extend=30):
     t = np.ascontiguousarray(np.append(t, 0).astype(np.uint8)); q = np.ascontiguousarray(np.append(q, 0).astype(np.uint8))
     segs = np.ascontiguousarray(segs.copy())
     out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
-    rc = L.emul_gapped_extend(t.ctypes.data, len(t) - 1, q.ctypes.data, len(q) - 1, sub.ctypes.data, 400, 30, ydrop, thresh,
+    rc = L.emul_gapped_extend(t.ctypes.data, len(t) - 1, q.ctypes.data, len(q) - 1, sub.ctypes.data, gap_open, gap_extend, ydrop, thresh,
                               tb_len, segs.ctypes.data, len(segs), 1, window, tb_slot,
                               C.byref(out), C.byref(n), C.byref(ops), C.byref(nops))
     assert rc == 0, rc
@@ -40,8 +40,8 @@ def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3
         C.memmove(al.ctypes.data, out, n.value * al.itemsize)
     if nops.value:
         C.memmove(op.ctypes.data, ops, nops.value * 4)
-    st = (C.c_uint64 * 7)(); L.emul_gapped_stats(st)
-    return al, op, dict(zip(("anchors", "anchors_extended", "dp_runs", "dp_cells", "rounds", "reruns", "retries"), st))
+    st = (C.c_uint64 * 8)(); L.emul_gapped_stats(st)
+    return al, op, dict(zip(("anchors", "anchors_extended", "dp_runs", "dp_cells", "rounds", "reruns", "retries", "wide_runs"), st))
 
 
 def _check(L, t, q, **kw):
@@ -52,7 +52,7 @@ def _check(L, t, q, **kw):
         hsps, _ = lzo.seed_hit_search(tab, qq, masked)
         segs = lzo.hsps_to_segments(hsps, rev)
         oal, oops, ost = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), ydrop=kw.get("ydrop", 9400),
-                                           tb_size=kw.get("tb_len", 0))
+                                           tb_size=kw.get("tb_len", 0), gap_open=kw.get("gap_open", 400), gap_extend=kw.get("gap_extend", 30))
         eal, eops, est = emul_gapped(L, t, qq, sub, segs.view(lzgpu.SEG_DTYPE), **kw)
         assert len(oal) == len(eal) and (oal == eal).all() and (oops == eops).all()
         assert est["dp_cells"] == ost["dp_cells"] and est["anchors_extended"] == ost["anchors_extended"]
@@ -96,3 +96,14 @@ def test_traceback_truncation_rule(L):
     """the reference truncates an alignment when its traceback arena runs out (:3640-3661)"""
     t, q = H.load_case("synth_overlap")
     _check(L, t, q, tb_len=1 << 20)
+
+
+@pytest.mark.parametrize("kw", [dict(ydrop=60000), dict(gap_open=200, gap_extend=5), dict(gap_open=300, gap_extend=12, ydrop=12000)],
+                         ids=["ydrop60000", "O200E5", "O300E12-mixed"])
+def test_bands_wider_than_the_lds_ring(L, kw):
+    """bands the 2048-column LDS ring cannot hold re-run in the HBM-ring variant of the same DP (k_ydrop_wide) instead
+    of declining the stage: huge y-drops, small gap-extension penalties"""
+    tgt = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+    _, q = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))[0]
+    st = _check(L, tgt, q, **kw)
+    assert st["wide_runs"] > 0

@@ -79,6 +79,34 @@ def test_thresholds_ydrop_truncation_vs_oracle(gpu):
             assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
 
 
+@pytest.mark.parametrize("kw", [dict(ydrop=60000), dict(gap_open=200, gap_extend=5), dict(gap_open=300, gap_extend=12, ydrop=12000)],
+                         ids=["ydrop60000", "O200E5", "O300E12-mixed"])
+def test_bands_wider_than_the_lds_ring(gpu, kw):
+    """bands the 2048-column LDS ring cannot hold run in k_ydrop_wide (ring in an HBM slot) -- the stage is no longer
+    declined for them; synth_overlap has 200 kbp of overlapping alignments that bound each other"""
+    sub, masked = H.scoring()
+    gpu.profile_enable(True); gpu.profile_reset()
+    for case in ("pseudo", "synth_overlap"):
+        if case == "pseudo":
+            t = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudocat.fa"))[0][1]
+            q = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))[0][1]
+        else:
+            t, q = H.load_case(case)
+            t, q = t[:60000], q[:60000]
+        gpu.table_prepare(t, gpu.seed(), CTB)
+        tab = lzo.Table(t, lzo.seed())
+        for _, rev, qq in H.strands(q):
+            hsps, _ = lzo.seed_hit_search(tab, qq, masked)
+            segs = lzo.hsps_to_segments(hsps, rev)
+            oal, oops, ost = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), **kw)
+            gpu.counters_reset()
+            al, ops = gpu.gapped_extend(sub, segs.view(lzgpu.SEG_DTYPE), q=qq, **kw)
+            assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
+            assert gpu.counters()["dp_cells"] == ost["dp_cells"]
+    prof = gpu.profile(); gpu.profile_enable(False)
+    assert prof.get("k_ydrop_wide", {"launches": 0})["launches"] > 0
+
+
 def test_two_mbp_pair_vs_oracle(gpu):
     t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=12)
     sub, masked = H.scoring()

@@ -72,6 +72,17 @@ def test_same_bytes_as_pristine_binary(sandbox, fmt):
 
 
 @needs_bins
+def test_wide_bands_stay_on_the_gpu(sandbox):
+    """O=200 E=5 needs bands of > 2048 columns: the HBM-ring DP runs them (round 1 declined the whole stage)"""
+    args = ["../test_data/pseudocat.fa", "../test_data/pseudopig.fa", "O=200", "E=5", "--format=axt"]
+    a, err = run(GPU_BIN, args, sandbox / "src", {"LZGPU_VERBOSE": "1"})
+    b, _ = run(REF_BIN, args, sandbox / "src")
+    assert err.count("[lzgpu] gapped: done on the GPU") == 6 and "declined" not in err, err[-1500:]
+    strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+    assert strip(a) == strip(b) and len(a) > 2000
+
+
+@needs_bins
 def test_table_cache_directory(sandbox, tmp_path):
     """LZGPU_TABLE_CACHE: the first run writes the target's table file, the second loads it; same bytes out."""
     t, q = seqio.synth_pair(400_000, 300_000, seed=43)
