@@ -190,6 +190,11 @@ typedef struct lz_gapped_args {
        declined (the reference adds trivial alignments for those, :1191-1290).                      */
     const uint32_t* sep1;  uint32_t n_sep1;
     const uint32_t* sep2;  uint32_t n_sep2;
+    /* identical sequences (identical_sequences, src/gapped_extend.c:1886-1933: same length, same bases
+       ignoring case, same strand flags): the trivial self-alignment goes in front of every anchor, as in
+       :1152-1189, and is dropped from the output when inhibit_trivial is set (:1483).                  */
+    int32_t        strands_differ; /* seq1->revCompFlags != seq2->revCompFlags                    */
+    int32_t        inhibit_trivial;/* gapped_extend's inhibitTrivial                              */
 } lz_gapped_args;
 
 typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */

@@ -328,6 +328,7 @@ alignel* gapped_extend
 	a.ydrop = yDrop;  a.score_thresh = scoreThresh.s;  a.traceback_bytes = tb->size;
 	a.anchors = segs;  a.n_anchors = anchors->len;  a.reduce = 0;   /* reduce_to_points already ran, src/lastz.c:3401 */
 
+	a.strands_differ = (seq1->revCompFlags != seq2->revCompFlags);  a.inhibit_trivial = (inhibitTrivial != 0);
 	sep1 = partition_separators (seq1, &a.n_sep1);  a.sep1 = sep1;
 	sep2 = partition_separators (seq2, &a.n_sep2);  a.sep2 = sep2;
 

@@ -380,6 +380,7 @@ extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint
     G.gap_open = a->gap_open; G.gap_extend = a->gap_extend; G.ydrop = a->ydrop; G.score_thresh = a->score_thresh;
     G.window = g_dp_window;
     G.sep1 = a->sep1; G.n_sep1 = a->sep1 ? a->n_sep1 : 0; G.sep2 = a->sep2; G.n_sep2 = a->sep2 ? a->n_sep2 : 0;
+    G.strands_differ = a->strands_differ != 0; G.inhibit_trivial = a->inhibit_trivial != 0;
     if ((a->sep1 && a->n_sep1 < 2) || (a->sep2 && a->n_sep2 < 2)) return lz_fail(LZGPU_ERR_ARG, "a partitioned sequence needs at least two separators");
     if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
     if (a->reduce) lzh_reduce_to_points(G.t, G.q, G.sub, a->anchors, a->n_anchors);

@@ -294,10 +294,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 {
     out.clear(); out_ops.clear();
     memset(&st, 0, sizeof(st));
-    // identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() of the bytes and, on a match, puts the
-    // trivial self-alignment in front of every anchor (:1152-1189, not restated here): such a pair is declined.  The
-    // test here folds the case of every ASCII letter -- a superset of dna_toupper's, so it can only decline more.
-    if (G.tlen == G.qlen && same_bases(G.t, G.q, G.tlen)) return LZGPU_NH_IDENTICAL;
+    // identical_sequences (src/gapped_extend.c:1886-1933): dna_toupper() of the bytes equal, same strand flags
+    const bool identical = !G.sep1 && !G.sep2 && !G.strands_differ && G.tlen == G.qlen && same_bases(G.t, G.q, G.tlen);
     // partitioned sequences: identical_partition_of_sequence / identical_partitioned_sequences (:1127-1147) make the
     // reference add trivial alignments; any pair of (partition | whole sequence) with the same bases is declined
     if (G.sep1 || G.sep2) {
@@ -324,8 +322,33 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     lap(t_sort);
 
     LzHostSnapshot S;
-    struct Info { s32 s; u32 beg1, beg2, end1, end2; std::vector<u32> script; };
+    struct Info { s32 s; u32 beg1, beg2, end1, end2; std::vector<u32> script; bool trivial = false; };
     std::vector<Info> info;                                    // parallel to S.aligns
+    if (identical && G.tlen > 0) {
+        // the trivial self-alignment bounds every anchor from the start, :1152-1189 (one diagonal segment; its
+        // score saturates at bestPossibleScore and is raised to the threshold "so it won't be discarded")
+        s32 sc = 0;
+        for (u32 i = 0; i < G.tlen; i++) {
+            u8 a = G.t[i], b = G.q[i];
+            if (a >= 'a' && a <= 'z') a -= 32;
+            if (b >= 'a' && b <= 'z') b -= 32;
+            const s32 w = G.sub[(u32)a * 256 + b];
+            if (sc == 0x7FFFFFFF) ;
+            else if (w <= 0 || sc < 0x7FFFFFFF - w) sc += w;
+            else sc = 0x7FFFFFFF;
+        }
+        LzDpAlign m; memset(&m, 0, sizeof(m));
+        m.pos1 = m.pos2 = 0; m.end1 = m.end2 = G.tlen - 1;
+        m.first_seg = m.last_seg = 0;
+        m.left_align1 = m.right_align1 = m.left_align2 = m.right_align2 = -1;
+        m.left_seg1 = m.right_seg1 = m.left_seg2 = m.right_seg2 = -1;
+        LzDpSeg g; g.b1 = g.b2 = 0; g.e1 = g.e2 = G.tlen - 1; g.type = LZ_DIAG_SEG;
+        S.segs.push_back(g); S.aligns.push_back(m);
+        Info in; in.s = sc < G.score_thresh ? G.score_thresh : sc; in.beg1 = in.beg2 = 1; in.end1 = in.end2 = G.tlen; in.trivial = true;
+        for (u32 left = G.tlen; left; ) { const u32 n = left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu; in.script.push_back((n << 2) | 3u); left -= n; }   // edit_script_sub
+        info.push_back(std::move(in));
+        insert_align(S, 0);
+    }
 
     const u32 W = G.window ? G.window : 1024;
     // Which anchors of a window are worth a speculative DP.  Most anchors lie on the alignment an
@@ -485,6 +508,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     for (s32 ai : S.obi) {
         const Info& in = info[ai];
         if (in.s < G.score_thresh) continue;
+        if (G.inhibit_trivial && in.trivial) continue;            // :1483
         lz_align a; a.beg1 = in.beg1; a.beg2 = in.beg2; a.end1 = in.end1; a.end2 = in.end2; a.s = in.s;
         a.script_len = (u32)in.script.size(); a.script_off = (u32)out_ops.size();
         out_ops.insert(out_ops.end(), in.script.begin(), in.script.end());

@@ -39,7 +39,8 @@ class GappedArgs(C.Structure):
                 ("sub", C.c_void_p), ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
                 ("ydrop", C.c_int32), ("score_thresh", C.c_int32), ("traceback_bytes", C.c_uint32),
                 ("anchors", C.c_void_p), ("n_anchors", C.c_uint32), ("reduce", C.c_int32),
-                ("sep1", C.c_void_p), ("n_sep1", C.c_uint32), ("sep2", C.c_void_p), ("n_sep2", C.c_uint32)]
+                ("sep1", C.c_void_p), ("n_sep1", C.c_uint32), ("sep2", C.c_void_p), ("n_sep2", C.c_uint32),
+                ("strands_differ", C.c_int32), ("inhibit_trivial", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -238,9 +239,10 @@ class Lib:
 
     # ---- B3
     def gapped_extend(self, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400,
-                      score_thresh=3000, traceback_bytes=0, reduce=True, sep1=None, sep2=None):
+                      score_thresh=3000, traceback_bytes=0, reduce=True, sep1=None, sep2=None, strands_differ=False, inhibit_trivial=False):
         """sep1 / sep2: positions of the NUL bytes bounding the partitions of a [multi] target / query"""
         a = GappedArgs()
+        a.strands_differ, a.inhibit_trivial = int(strands_differ), int(inhibit_trivial)
         if sep1 is not None:
             sep1 = np.ascontiguousarray(sep1, dtype=np.uint32); a.sep1, a.n_sep1 = sep1.ctypes.data, len(sep1)
         if sep2 is not None:

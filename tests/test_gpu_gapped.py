@@ -137,17 +137,23 @@ def test_two_mbp_pair_vs_oracle(gpu):
             assert s == a["s"]
 
 
-def test_identical_sequences_decline_case_insensitively(gpu):
-    """identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() bytes: a target paired with a
-    soft-masked copy of itself must take the reference's trivial-alignment path, i.e. be declined (> 0) here"""
+def test_identical_sequences_get_the_trivial_alignment(gpu):
+    """identical_sequences (src/gapped_extend.c:1886-1933) compares dna_toupper() bytes and the strand flags: the
+    trivial self-alignment is put in front of every anchor (:1152-1189), so anchors on the main diagonal vanish;
+    inhibit_trivial drops it from the output (:1483); the byte-for-byte check against the reference binary is
+    tests/test_gpu_lastz_cli.py::test_identical_sequences"""
     sub, _ = H.scoring()
     t, _ = seqio.synth_pair(50000, 100, seed=3)
     gpu.table_prepare(t, gpu.seed(), CTB)
     segs = np.zeros(1, dtype=lzgpu.SEG_DTYPE); segs["pos1"] = 1000; segs["pos2"] = 1000; segs["length"] = 100; segs["s"] = 9000
     for q in (t.copy(), t | 0x20, np.where(np.arange(len(t)) % 3 == 0, t | 0x20, t).astype(np.uint8)):
-        with pytest.raises(lzgpu.NotHandled) as e:
-            gpu.gapped_extend(sub, segs.copy(), q=q)
-        assert e.value.rc == 6
-    q = t.copy(); q[777] = ord("A") if q[777] != ord("A") else ord("C")     # one base apart: handled
+        al, ops = gpu.gapped_extend(sub, segs.copy(), q=q)
+        assert len(al) == 1 and tuple(al[0][["beg1", "beg2", "end1", "end2"]]) == (1, 1, 50000, 50000)
+        assert list(ops) == [(50000 << 2) | 3] and al[0]["s"] == int(sub[t & 0xDF, t & 0xDF].sum())
+        al, ops = gpu.gapped_extend(sub, segs.copy(), q=q, inhibit_trivial=True)
+        assert len(al) == 0
+    al, _ = gpu.gapped_extend(sub, segs.copy(), q=t.copy(), strands_differ=True)     # not "identical" for the reference
+    assert len(al) == 1 and al[0]["s"] > 0
+    q = t.copy(); q[777] = ord("A") if q[777] != ord("A") else ord("C")     # one base apart: an ordinary pair
     al, _ = gpu.gapped_extend(sub, segs.copy(), q=q)
     assert len(al) == 1

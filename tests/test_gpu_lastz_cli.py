@@ -83,6 +83,29 @@ def test_wide_bands_stay_on_the_gpu(sandbox):
 
 
 @needs_bins
+@pytest.mark.parametrize("extra", [[], ["--notrivial"], ["--format=maf", "--strand=plus"]], ids=["plain", "notrivial", "maf-plus"])
+def test_identical_sequences(sandbox, extra):
+    """a sequence against itself WITHOUT --self, and against a soft-masked copy: the trivial self-alignment path
+    (src/gapped_extend.c:1152-1189) runs on the GPU and gives the pristine binary's bytes"""
+    t, _ = seqio.synth_pair(300_000, 1000, seed=51)
+    t[100_000:130_000] = t[20_000:50_000]                       # a repeat: off-diagonal alignments bounded by the trivial one
+    seqio.write_fasta(sandbox / "ti.fa", [("same", t)])
+    m = t.copy(); m[5000:9000] |= 0x20
+    seqio.write_fasta(sandbox / "tim.fa", [("same", m)])
+    for q in ("ti.fa", "tim.fa"):
+        args = ["ti.fa", q, "--ydrop=9430"] + extra
+        a, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+        b, _ = run(REF_BIN, args, sandbox)
+        assert "[lzgpu] gapped: done on the GPU" in err and "declined" not in err, err[-1500:]
+        if "--format=maf" in extra:
+            strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+            assert strip(a) == strip(b)
+        else:
+            assert normalize_lav(a) == normalize_lav(b)
+        assert len(a) > 300
+
+
+@needs_bins
 def test_table_cache_directory(sandbox, tmp_path):
     """LZGPU_TABLE_CACHE: the first run writes the target's table file, the second loads it; same bytes out."""
     t, q = seqio.synth_pair(400_000, 300_000, seed=43)
