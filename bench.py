@@ -355,7 +355,7 @@ def run_single(a, torch, lib):
     # (phase A = k_probe_part, which scans every hit and partitions the records), the diagEnd read / write per hit /
     # extension (phase B = k_settle, which settles hits from the summaries)
     V = sd.num_probes
-    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_probe_part": X, "k_settle": 4 * Hh + 4 * E}
+    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_scan_hits": X, "k_settle": 4 * Hh + 4 * E}
     b_seed = W * (1 + 4 * V) + 8 * Hh + 4 * E + X
     kern_ms = {k: v["ms"] / K for k, v in prof.items()}
     dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k], default=None)

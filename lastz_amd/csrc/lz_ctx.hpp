@@ -50,12 +50,13 @@ struct SeqSlot {                    // a sequence resident in HBM
     u8* code_base() const { return code.as<u8>() + LZ_SEQ_PAD; }
 };
 
+#define LZ_SETS 3                       // sets of the per-chunk buffers (the chunk pipeline of lzgpu_seed_hit_search)
 struct LzCtx {
     bool inited = false;
     int  device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // phase B of chunk c overlaps fill/probe/sort of chunk c+1
-    hipEvent_t ev_sorted[2] = { nullptr, nullptr }, ev_extended[2] = { nullptr, nullptr }, ev_init = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;   // chunk pipeline: fill + histogram (stream) | scans (stream3) | partition + phase B (stream2)
+    hipEvent_t ev_keys[LZ_SETS] = {}, ev_summ[LZ_SETS] = {}, ev_part[LZ_SETS] = {}, ev_extended[LZ_SETS] = {}, ev_init = nullptr;
     std::string last_error;
 
     // ---- target + position table (B1)
@@ -73,10 +74,11 @@ struct LzCtx {
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
     DevBuf wiv, wsk, wsv;           // position index; (word, position) sorted by word
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
-    DevBuf keys_a;                  // hit keys of the current chunk, discovery order
-    DevBuf recs[2], bin_base[2];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
+    DevBuf keys[LZ_SETS];                 // hit keys of a chunk, discovery order (two sets of every per-chunk buffer: the chunk pipeline)
+    DevBuf recs[LZ_SETS], bin_base[LZ_SETS];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
                                     // phase B of a chunk runs while the next chunk is filled / scanned / partitioned
-    DevBuf hist, hist_part;         // per-tile partition histogram and its block sums
+    DevBuf hist[LZ_SETS], hist_part[LZ_SETS];   // per-tile partition histogram and its block sums
+    DevBuf summ[LZ_SETS], scan_tasks[LZ_SETS], scan_ntasks[LZ_SETS];   // phase A: 4-byte summary per hit of the chunk; the scans that go on past their first window
     DevBuf lut;                     // phase-A tables (lz_lut.hpp)
     DevBuf sort_tmp, scan_tmp;
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
@@ -109,14 +111,16 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);   // honours c.n_owners / c.owner
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out);
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys);
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 struct LzLutParams; struct LzLutEntry;
 #define LZ_PP_TILE_HOST 2048        // hits per tile of k_hist / k_probe_part (sizes the partition histogram)
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
-int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base);
-int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                   const s32* score_tab, const LzLutEntry* lut, const u32* hist, const u32* part, u64* recs);
+int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
+int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);
+int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
+                  const s32* score_tab, const LzLutEntry* lut, hipStream_t st);     // -> c.summ[set]
+int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, const u32* part, u64* recs, hipStream_t st);
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

@@ -32,9 +32,15 @@ int lz_fail(int code, const char* fmt, ...)
 int DevBuf::ensure(size_t bytes)
 {
     if (bytes <= cap && p) return 0;
+    static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t old = cap;
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const auto t1 = std::chrono::steady_clock::now();
     size_t want = bytes < 256 ? 256 : bytes;
     hipError_t e = hipMalloc(&p, want);
+    if (prof && want >= (64u << 20)) fprintf(stderr, "[lzgpu hostprof] device buffer %zu -> %zu MiB: hipFree %.1f ms, hipMalloc %.1f ms\n", old >> 20, want >> 20,
+                                             std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     if (e != hipSuccess) { p = nullptr; return lz_fail(LZGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
     cap = want;
     return 0;
@@ -130,8 +136,11 @@ extern "C" int lzgpu_init(int device_index)
     LZ_HIP(hipSetDevice(device_index));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_sorted[k], hipEventDisableTiming));
+    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream3, hipStreamNonBlocking));
+    for (int k = 0; k < LZ_SETS; k++) {
+        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_keys[k], hipEventDisableTiming));
+        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_summ[k], hipEventDisableTiming));
+        LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_part[k], hipEventDisableTiming));
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_extended[k], hipEventDisableTiming));
     }
     LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_init, hipEventDisableTiming));
@@ -149,21 +158,27 @@ extern "C" void lzgpu_shutdown(void)
     (void)hipStreamSynchronize(c.stream);
     lz_phase_clocks_print();
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
+    if (c.stream3) (void)hipStreamSynchronize(c.stream3);
     c.timer.resolve();
     if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
-    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.keys_a, &c.recs[0], &c.recs[1], &c.bin_base[0], &c.bin_base[1], &c.hist, &c.hist_part, &c.lut,
+    DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.lut,
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
+    for (int k = 0; k < LZ_SETS; k++) { DevBuf* sb[] = { &c.keys[k], &c.recs[k], &c.bin_base[k], &c.hist[k], &c.hist_part[k], &c.summ[k], &c.scan_tasks[k], &c.scan_ntasks[k] }; for (DevBuf* b : sb) b->release(); }
     for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); kv.second.two.release(); kv.second.spc.release(); kv.second.occ_dev.release(); }
     c.target.dp.release(); c.target.nib.release(); c.target.two.release(); c.target.spc.release(); c.target.occ_dev.release();
     lz_release_statics();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
     if (c.stream2) (void)hipStreamDestroy(c.stream2);
-    for (int k = 0; k < 2; k++) { if (c.ev_sorted[k]) (void)hipEventDestroy(c.ev_sorted[k]); if (c.ev_extended[k]) (void)hipEventDestroy(c.ev_extended[k]); c.ev_sorted[k] = c.ev_extended[k] = nullptr; }
+    if (c.stream3) (void)hipStreamDestroy(c.stream3);
+    for (int k = 0; k < LZ_SETS; k++) {
+        hipEvent_t* ev[] = { &c.ev_keys[k], &c.ev_summ[k], &c.ev_part[k], &c.ev_extended[k] };
+        for (hipEvent_t* e : ev) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    }
     if (c.ev_init) (void)hipEventDestroy(c.ev_init);
-    c.ev_init = nullptr; c.stream2 = nullptr;
+    c.ev_init = nullptr; c.stream2 = nullptr; c.stream3 = nullptr;
     c.stream = nullptr; c.inited = false; c.have_table = false; c.device = -1;
     c.n_owners = 1; c.owner = 0; c.last_order.clear();
 }
@@ -508,17 +523,20 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     g_hp.lap(2, "chunk plan");
     u64 max_chunk = 0;
     for (auto& ch : chunks) if (ch.nh > max_chunk) max_chunk = ch.nh;
-    const int nsets = chunks.size() > 1 ? 2 : 1;
+    // LZGPU_OVERLAP=1: the chunk pipeline over three streams (below); default: one stream, one buffer set
+    static const bool overlap = getenv("LZGPU_OVERLAP") != nullptr && getenv("LZGPU_SERIAL") == nullptr;
+    const int nsets = overlap ? (int)std::min<size_t>(chunks.size() ? chunks.size() : 1, LZ_SETS) : 1;
     if (max_chunk) {
-        if ((rc = c.keys_a.ensure((size_t)max_chunk * 8))) return rc;
+        if ((rc = c.keys[0].ensure((size_t)max_chunk * 8))) return rc;
         if (a->extend) {
             const size_t ntiles = (size_t)((max_chunk + LZ_PP_TILE_HOST - 1) / LZ_PP_TILE_HOST), nblocks = (ntiles + 255) / 256;
             for (int k = 0; k < nsets; k++) {
+                if ((rc = c.keys[k].ensure((size_t)max_chunk * 8))) return rc;
                 if ((rc = c.recs[k].ensure((size_t)max_chunk * 8))) return rc;
                 if ((rc = c.bin_base[k].ensure(257 * 4))) return rc;
+                if ((rc = c.hist[k].ensure(ntiles * 256 * 4))) return rc;
+                if ((rc = c.hist_part[k].ensure(nblocks * 256 * 4))) return rc;
             }
-            if ((rc = c.hist.ensure(ntiles * 256 * 4))) return rc;
-            if ((rc = c.hist_part.ensure(nblocks * 256 * 4))) return rc;
         }
     }
     const u32 out_cap = (u32)std::min<u64>(c.hsp_capacity, 0xFFFFFFF0ull);
@@ -557,39 +575,69 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     c.last_scan_mode = mode;
 
     std::vector<lz_hsp> plain;
-    // ---- 3. per chunk: fill -> partition offsets -> (phase A scans + stable partition) -> phase B per partition
+    // ---- 3. per chunk, a three-stage pipeline over three streams and two sets of every per-chunk buffer:
+    //   stream  (F): k_fill_hits -> k_hist + scans            keys, partition offsets           memory-bound
+    //   stream3 (S): k_scan_hits -> k_scan_tasks              phase A, the 4-byte summaries     VALU-bound
+    //   stream2 (B): k_partition -> k_settle                  records in partitions, phase B    latency-bound
+    // so that chunk c's phase B, chunk c+1's scans and chunk c+2's fill share the CUs (the scan kernel leaves
+    // LDS, registers and wave slots for the others' workgroups).  Phase B launches are ordered among themselves
+    // on stream2 (diagEnd carries from chunk to chunk); a buffer set is rewritten only after its last reader.
+    if (a->extend && max_chunk) for (int k = 0; k < nsets; k++) if ((rc = lzk_scan_reserve(c, k, mode, max_chunk))) return rc;
     LZ_HIP(hipEventRecord(c.ev_init, c.stream));              // state resets above are on stream 1
     LZ_HIP(hipStreamWaitEvent(c.stream2, c.ev_init, 0));
+    LZ_HIP(hipStreamWaitEvent(c.stream3, c.ev_init, 0));
     size_t ci = 0;
-    // LZGPU_SERIAL=1 (profiling aid): phase B on stream 1 too, so that per-kernel event times are not
-    // inflated by the other stream's kernels sharing the CUs
-    static const bool serial = getenv("LZGPU_SERIAL") != nullptr;
-    hipStream_t sB = serial ? c.stream : c.stream2;
+    // Measured on the bench pair: 219-223 ms per step with the pipeline, 226 ms with everything on one stream --
+    // the scan kernel runs at 75-85 % of the VALU issue rate, ~75 % LDS-pipe occupancy and 3 TB/s of 64-byte
+    // sector fetches at once, so co-resident kernels mostly take turns with it.  The pipeline therefore is opt-in
+    // (LZGPU_OVERLAP=1): by default the stage runs on one stream with one buffer set (5 GiB less to allocate,
+    // per-kernel event times that mean what they say).
+    const bool serial = !overlap;
+    hipStream_t sF = c.stream, sS = serial ? c.stream : c.stream3, sB = serial ? c.stream : c.stream2;
+    // phase B needs whole CUs (128 VGPRs x 1024 lanes) and cannot share one with the scan kernel: it runs on the
+    // scans' stream, behind the NEXT chunk's scans, by which time its partition (which does overlap them) is done
+    auto settle = [&](int set) -> int {
+        LZ_HIP(hipStreamWaitEvent(sS, c.ev_part[set], 0));
+        int r = lzk_settle(c, P, c.recs[set].as<u64>(), c.bin_base[set].as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
+                           c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, sS);
+        if (r) return r;
+        LZ_HIP(hipEventRecord(c.ev_extended[set], sS));
+        return 0;
+    };
+    int pending = -1;                                           // set whose phase B is still to be launched
     for (auto& ch : chunks) {
-        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys_a.as<u64>()))) return rc;
+        const int set = (int)(ci % (size_t)nsets);
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
+            if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[0].as<u64>(), sF))) return rc;
             std::vector<u64> hk(ch.nh);
-            LZ_HIP(hipMemcpyAsync(hk.data(), c.keys_a.p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));
+            LZ_HIP(hipMemcpyAsync(hk.data(), c.keys[0].p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));
             LZ_HIP(hipStreamSynchronize(c.stream));
             for (u64 k : hk) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); }
             continue;
         }
-        // Phase B of this chunk runs on stream2 while stream 1 already fills / scans / partitions the next
-        // chunk (two record sets).  Phase B launches are ordered among themselves on stream2 (diagEnd
-        // carries from chunk to chunk); a set is rewritten only after the phase B that read it is done.
-        const int set = (int)(ci & 1) % nsets;
-        if (ci >= 2) LZ_HIP(hipStreamWaitEvent(c.stream, c.ev_extended[set], 0));
-        if ((rc = lzk_hist(c, c.keys_a.as<u64>(), ch.nh, c.hist.as<u32>(), c.hist_part.as<u32>(), c.bin_base[set].as<u32>()))) return rc;
-        if ((rc = lzk_probe_part(c, mode, P, Q, c.keys_a.as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(),
-                                 c.hist.as<u32>(), c.hist_part.as<u32>(), c.recs[set].as<u64>()))) return rc;
-        LZ_HIP(hipEventRecord(c.ev_sorted[set], c.stream));
-        LZ_HIP(hipStreamWaitEvent(sB, c.ev_sorted[set], 0));
-        if ((rc = lzk_settle(c, P, c.recs[set].as<u64>(), c.bin_base[set].as<u32>(), c.diag_end.as<u32>(), c.score_tab.as<s32>(),
-                             c.hsp_out.as<LzHspRec>(), c.hsp_count.as<u32>(), out_cap, d_counters, sB))) return rc;
-        LZ_HIP(hipEventRecord(c.ev_extended[set], sB));
+        const bool reuse = ci >= (size_t)nsets;                 // the set has been through the pipeline before
+        if (reuse && pending == set) { if ((rc = settle(pending))) return rc; pending = -1; }   // (fewer than three sets)
+        // F: keys + histogram (every buffer of the set is free once its phase B is done)
+        if (reuse) LZ_HIP(hipStreamWaitEvent(sF, c.ev_extended[set], 0));
+        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[set].as<u64>(), sF))) return rc;
+        if ((rc = lzk_hist(c, c.keys[set].as<u64>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.bin_base[set].as<u32>(), sF))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_keys[set], sF));
+        // S: the scans
+        LZ_HIP(hipStreamWaitEvent(sS, c.ev_keys[set], 0));
+        if ((rc = lzk_scan_hits(c, set, mode, P, Q, c.keys[set].as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(), sS))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_summ[set], sS));
+        // B: the partition
+        LZ_HIP(hipStreamWaitEvent(sB, c.ev_summ[set], 0));
+        if ((rc = lzk_partition(c, set, c.keys[set].as<u64>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.recs[set].as<u64>(), sB))) return rc;
+        LZ_HIP(hipEventRecord(c.ev_part[set], sB));
+        // S again: phase B of the previous chunk (diagEnd carries from chunk to chunk: chunk order)
+        if (pending >= 0) { if ((rc = settle(pending))) return rc; }
+        pending = set;
         ci++;
     }
+    if (pending >= 0) { if ((rc = settle(pending))) return rc; }
     g_hp.lap(3, "chunk loop launches");
+    LZ_HIP(hipStreamSynchronize(c.stream3));
     LZ_HIP(hipStreamSynchronize(c.stream2));
     g_hp.lap(4, "wait for GPU");
 

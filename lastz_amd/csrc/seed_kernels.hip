@@ -372,17 +372,17 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
     }
 }
 
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys)
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st)
 {
     if (n == 0 || i1 <= i0) return 0;
-    c.timer.begin("k_fill_hits", c.stream);
+    c.timer.begin("k_fill_hits", st);
     if (c.n_owners > 1)
-        hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+        hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
                            lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, c.n_owners, c.owner);
     else
-        hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+        hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
                            lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, 1u, 0u);
-    c.timer.end(c.stream);
+    c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
 }
@@ -519,16 +519,16 @@ k_hist_scan2(u32* __restrict__ part, u32 nblocks, u32* __restrict__ bin_base)
     for (u32 b = 0; b < nblocks; b++) part[(size_t)b * LZ_NBIN + threadIdx.x] += bb;
 }
 
-int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base)
+int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st)
 {
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE), nblocks = (ntiles + 255u) / 256u;
-    c.timer.begin("k_hist", c.stream);
-    hipLaunchKernelGGL(k_hist, dim3(ntiles), dim3(LZ_TPB), 0, c.stream, keys, n, hist);
-    c.timer.end(c.stream);
-    c.timer.begin("k_hist_scan", c.stream);
-    hipLaunchKernelGGL(k_hist_scan1, dim3(nblocks), dim3(LZ_NBIN), 0, c.stream, hist, ntiles, part);
-    hipLaunchKernelGGL(k_hist_scan2, dim3(1), dim3(LZ_NBIN), 0, c.stream, part, nblocks, bin_base);
-    c.timer.end(c.stream);
+    c.timer.begin("k_hist", st);
+    hipLaunchKernelGGL(k_hist, dim3(ntiles), dim3(LZ_TPB), 0, st, keys, n, hist);
+    c.timer.end(st);
+    c.timer.begin("k_hist_scan", st);
+    hipLaunchKernelGGL(k_hist_scan1, dim3(nblocks), dim3(LZ_NBIN), 0, st, hist, ntiles, part);
+    hipLaunchKernelGGL(k_hist_scan2, dim3(1), dim3(LZ_NBIN), 0, st, part, nblocks, bin_base);
+    c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
 }
@@ -563,68 +563,60 @@ __device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
     return pre + inc - v;
 }
 
-// One workgroup of 512 lanes per tile of 2048 hits (a wave owns 256 consecutive hits, 64 at a time), two
-// workgroups per CU (78 KiB of LDS each: one 32 KiB table serves both scan directions), so that one workgroup's
-// barriers, queue drain and write-out overlap the other's scans.  The kernel is a sequence of short rolled loops
-// over the four rounds; what a hit needs from one loop to the next travels through LDS (info[]), so that the
-// heavy code -- the unrolled, branch-free window of lz_lut.hpp -- exists four times only (head and continuation,
-// left and right).
-struct LzPPTask { u32 s; s32 run, best; u32 room, used, nwin; s32 diag; u32 li_side; };
-#define LZ_PP_INFO(used, alive, best) (((used) & 0xFFu) | (((alive) & 3u) << 8) | ((u32)(best) << 16))
-struct LzPPShared {
+// ---- phase A + the partition, three kernels:
+//   k_scan_hits   every hit's two scans, first window each (the heavy, branch-free code of lz_lut.hpp): a pure
+//                 stream -- a wave takes 256 consecutive hits, 64 at a time, with the next 64 hits' windows in
+//                 flight -- with no barrier and nothing in LDS but the 32 KiB table, so every resident wave is in
+//                 this code all the time.  Output: the 4-byte summary of a hit whose scans both ended; the rare hit
+//                 with a scan that goes on (~3 %) becomes a 64-byte task in a global list (one atomic per wave).
+//   k_scan_tasks  one lane per task: the scans that go on, to their end or the LZ_LUT_MAXWIN cap; full waves.
+//   k_partition   keys + summaries -> records, stably partitioned into the 256 streams (tile histogram of k_hist).
+// (One fused kernel did all of this per tile behind barriers: its workgroups spent half their time in the light
+// phases -- queue drain on two waves, ranks, write-out -- while holding the LDS and the wave slots the scans need.)
+struct LzScanTask { u32 idx; s32 diag; LzLutScan L, R; };
+static_assert(sizeof(LzScanTask) == 64, "LzScanTask: one 64-byte line per task");
+#define LZ_SC_TPB 512
+struct LzScanShared {
     union {
         LzLutEntry lut[LZ_LUT_ENTRIES];                                 // MODE 0/1: the look-up table (32 KiB)
         struct { s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64]; } bc;    // MODE 2: the byte-code scans' tables
     };
-    u32 info[2 * LZ_PP_TILE];                        // per hit: left / right scan: bases consumed | alive << 8 | best << 16 (MODE 2: the summary)
-    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition (the partition rides in bits 55..62)
-    u32 wcnt[LZ_PP_WAVES][LZ_NBIN];                  // per wave and partition: records / running offset inside the partition
-    u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
-    LzPPTask q[LZ_PP_QCAP]; u32 qn;
 };
-static_assert(LZ_PP_TILE == LZ_PP_TILE_HOST && sizeof(LzPPShared) <= 80 * 1024, "LDS budget of k_probe_part: two workgroups per CU");
 
 template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
-__global__ void __launch_bounds__(LZ_PP_TPB)
-k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n, u32 ntiles,
-             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
-             const u32* __restrict__ hist, const u32* __restrict__ part, u64* __restrict__ recs)
+__global__ void __launch_bounds__(LZ_SC_TPB)
+k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n,
+            const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
+            u32* __restrict__ summ, LzScanTask* __restrict__ tasks, u32* __restrict__ n_tasks, u32 region_cap)
 {
-    __shared__ LzPPShared sh;
+    __shared__ LzScanShared sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_ENTRIES; k += LZ_PP_TPB) sh.lut[k] = lut_g[k]; }
+    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_ENTRIES; k += LZ_SC_TPB) sh.lut[k] = lut_g[k]; }
     else {
-        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_PP_TPB) sh.bc.tab[k] = score_tab_g[k];
+        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_SC_TPB) sh.bc.tab[k] = score_tab_g[k];
         if (tid < 64) sh.bc.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
     }
+    __syncthreads();
     const LzLutEntry* lut = sh.lut;
     constexpr bool SP = MODE == 1;
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const u64 base = (u64)tile * LZ_PP_TILE;
-        const u32 tile_n = (n - base < (u64)LZ_PP_TILE) ? (u32)(n - base) : (u32)LZ_PP_TILE;
-        LZ_CLK_DECL;
-        if (tid == 0) sh.qn = 0;
-        for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN; k += LZ_PP_TPB) (&sh.wcnt[0][0])[k] = 0;
-        __syncthreads();
-        LZ_CLK(0);
-
-        // ---- phase A, first window of both scans of every hit; a scan that goes on is queued.  The four keys of a
-        // lane are requested together and the windows of round r + 1 before round r is computed, so that the
-        // wave has its next loads in flight while it works.
-        constexpr bool HLIM = SP;                    // MODE 0 heads run without limit tests: a side with less than 60 bases of room is queued
+    constexpr bool HLIM = SP;                        // MODE 0 heads run without limit tests: a side with less than 60 bases of room becomes a task
+    constexpr u32 SPAN = 64u * LZ_PP_ROUNDS;
+    const u64 nspans = (n + SPAN - 1) / SPAN, wstride = (u64)gridDim.x * (LZ_SC_TPB / 64);
+    // the tasks of a wave go to the wave's own region of the list: no atomics, the count is written once at the end
+    const u32 region = blockIdx.x * (LZ_SC_TPB / 64) + w;
+    LzScanTask* const my_tasks = tasks + (size_t)region * region_cap;
+    u32 my_n = 0;
+    for (u64 span = (u64)blockIdx.x * (LZ_SC_TPB / 64) + w; span < nspans; span += wstride) {
+        const u64 base = span * SPAN;
+        const u32 span_n = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
         u64 k0, k1, k2, k3;
-        {
-            const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
-            k0 = (l0 < tile_n) ? keys[base + l0] : 0ull;             k1 = (l0 + 64u < tile_n) ? keys[base + l0 + 64u] : 0ull;
-            k2 = (l0 + 128u < tile_n) ? keys[base + l0 + 128u] : 0ull; k3 = (l0 + 192u < tile_n) ? keys[base + l0 + 192u] : 0ull;
-        }
+        k0 = (lane < span_n) ? keys[base + lane] : 0ull;               k1 = (lane + 64u < span_n) ? keys[base + lane + 64u] : 0ull;
+        k2 = (lane + 128u < span_n) ? keys[base + lane + 128u] : 0ull; k3 = (lane + 192u < span_n) ? keys[base + lane + 192u] : 0ull;
         if (MODE == 2) {
 #pragma unroll 1
             for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
-                const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
-                const bool valid = li < tile_n;
-                sh.info[2 * li] = valid ? lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, k0) : 0u;
-                if (valid) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(k0)], 1u);
+                const u32 li = r * 64u + lane;
+                if (li < span_n) summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, k0);
                 const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
             }
         } else {
@@ -633,8 +625,8 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
             lz_lut_fetch<false, SP>(Q, L.s, diag, rawl); lz_lut_fetch<true, SP>(Q, R.s, diag, rawr);
 #pragma unroll 1
             for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
-                const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
-                const bool valid = li < tile_n;
+                const u32 li = r * 64u + lane;
+                const bool valid = li < span_n;
                 // the next round's windows
                 s32 ndiag; LzLutScan NL, NR; LzLutRaw<SP> nrawl, nrawr;
                 lz_lut_init(k1, P.tlen, P.qlen, ndiag, NL, NR);
@@ -643,107 +635,163 @@ k_probe_part(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 
                 if (!valid) { L.alive = 0; R.alive = 0; }
                 const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
                 lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr);
-                if (L.alive == 1) {
-                    const u32 slot = atomicAdd(&sh.qn, 1u);          // (a full queue leaves the scan "alive": the hit becomes SLOW)
-                    if (slot < LZ_PP_QCAP) sh.q[slot] = { L.s, L.run, L.best, L.room, L.used, L.nwin, diag, (li << 1) | 0u };
+                const bool more = valid && (L.alive == 1 || R.alive == 1);
+                const u64 mm = __ballot(more);
+                bool queued = false;
+                if (mm) {                                                // (wave-uniform)
+                    const u32 slot = my_n + (u32)__popcll(mm & ((1ull << lane) - 1ull));
+                    if (more && slot < region_cap) {                     // (a full region leaves the scan "alive": the hit becomes SLOW)
+                        LzScanTask t; t.idx = (u32)(base + li); t.diag = diag; t.L = L; t.R = R;
+                        my_tasks[slot] = t; queued = true;
+                    }
+                    my_n += (u32)__popcll(mm);
                 }
-                if (R.alive == 1) {
-                    const u32 slot = atomicAdd(&sh.qn, 1u);
-                    if (slot < LZ_PP_QCAP) sh.q[slot] = { R.s, R.run, R.best, R.room, R.used, R.nwin, diag, (li << 1) | 1u };
-                }
-                sh.info[2 * li] = LZ_PP_INFO(L.used, L.alive, L.best);
-                sh.info[2 * li + 1] = LZ_PP_INFO(R.used, R.alive, R.best);
-                if (valid) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(k0)], 1u);         // the partition counts, per (wave, partition)
+                if (valid && !queued) summ[base + li] = lz_lut_summary(L, R, P.min_score);
                 const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
                 diag = ndiag; L = NL; R = NR; rawl = nrawl; rawr = nrawr;
             }
         }
-        LZ_CLK(1);
-        __syncthreads();
-        LZ_CLK(2);
-        if (MODE < 2) {
-            // ---- the queued scans, one lane per scan, to their end (or the cap of LZ_LUT_MAXWIN windows)
-            const u32 nq = sh.qn < (u32)LZ_PP_QCAP ? sh.qn : (u32)LZ_PP_QCAP;
-            for (u32 k = tid; k < nq; k += LZ_PP_TPB) {
-                const LzPPTask t = sh.q[k];
-                LzLutScan S; S.s = t.s; S.run = t.run; S.best = t.best; S.room = t.room; S.used = t.used; S.nwin = t.nwin; S.alive = 1;
-                while (S.alive == 1 && S.nwin < (u32)LZ_LUT_MAXWIN) {
-                    LzLutRaw<SP> raw;
-                    if (t.li_side & 1u) { lz_lut_fetch<true, SP>(Q, S.s, t.diag, raw);  lz_lut_window<true, SP, true>(Q, lut, t.diag, S, raw); }
-                    else                { lz_lut_fetch<false, SP>(Q, S.s, t.diag, raw); lz_lut_window<false, SP, true>(Q, lut, t.diag, S, raw); }
-                }
-                sh.info[t.li_side] = LZ_PP_INFO(S.used, S.alive, S.best);
-            }
-            LZ_CLK(3);
-            __syncthreads();
-            LZ_CLK(4);
+    }
+    if (lane == 0) n_tasks[region] = my_n < region_cap ? my_n : region_cap;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut_g, const LzScanTask* __restrict__ tasks,
+             const u32* __restrict__ n_tasks, u32 n_regions, u32 region_cap, u32* __restrict__ summ)
+{
+    __shared__ LzLutEntry lut[LZ_LUT_ENTRIES];
+    for (u32 k = threadIdx.x; k < LZ_LUT_ENTRIES; k += 256) lut[k] = lut_g[k];
+    __syncthreads();
+    constexpr bool SP = MODE == 1;
+    for (u32 region = blockIdx.x; region < n_regions; region += gridDim.x) {
+        const u32 nt = n_tasks[region];
+        for (u32 k = threadIdx.x; k < nt; k += 256u) {
+            const LzScanTask t = tasks[(size_t)region * region_cap + k];
+            LzLutScan L = t.L, R = t.R;
+            while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SP>(Q, lut, t.diag, L);
+            while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SP>(Q, lut, t.diag, R);
+            summ[t.idx] = lz_lut_summary(L, R, P.min_score);
         }
-        LZ_CLK(5);
-        // ... chained in wave order (= discovery order: a wave holds 256 consecutive hits) ...
-        u32 tot = 0;
-        if (tid < LZ_NBIN) {
-            for (u32 k = 0; k < LZ_PP_WAVES; k++) { const u32 v = sh.wcnt[k][tid]; sh.wcnt[k][tid] = tot; tot += v; }
-            sh.gbase[tid] = part[(size_t)(tile >> 8) * LZ_NBIN + tid] + hist[(size_t)tile * LZ_NBIN + tid];
-        }
-        const u32 ts = lz_exscan256(tot, sh.wtot);
-        if (tid < LZ_NBIN) sh.tstart[tid] = ts;
-        if (tid == 0) sh.tstart[LZ_NBIN] = tile_n;
-        __syncthreads();
-        LZ_CLK(6);
-        // ... then every record gets its place: rank among the same-partition lanes of its wave's round, on top of
-        // the wave's running offset (stable: lanes, rounds and waves all follow the discovery order)
-        {
-            const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
-            k0 = (l0 < tile_n) ? keys[base + l0] : 0ull;             k1 = (l0 + 64u < tile_n) ? keys[base + l0 + 64u] : 0ull;
-            k2 = (l0 + 128u < tile_n) ? keys[base + l0 + 128u] : 0ull; k3 = (l0 + 192u < tile_n) ? keys[base + l0 + 192u] : 0ull;
-        }
-#pragma unroll 1
-        for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
-            const u32 li = w * (64u * LZ_PP_ROUNDS) + r * 64u + lane;
-            const bool valid = li < tile_n;
-            const u64 key = k0;
-            { const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t; }
-            const u32 bin = LZ_KEY_BIN(key);
-            u32 rank, count; bool last;
-            lz_match8(bin, valid, lane, rank, count, last);
-            const u32 old = sh.wcnt[w][bin];
-            if (valid && last) sh.wcnt[w][bin] = old + count;
-            if (valid) {
-                u32 summ;
-                if (MODE == 2) summ = sh.info[2 * li];
-                else {
-                    const u32 il = sh.info[2 * li], ir = sh.info[2 * li + 1];
-                    summ = (il & 0xFFu) | ((ir & 0xFFu) << 8);
-                    if (((il | ir) & 0x300u) || (s32)((il >> 16) + (ir >> 16)) >= P.min_score) summ |= LZ_SUMM_SLOW;
-                }
-                const u32 pos = sh.tstart[bin] + old + rank;
-                sh.stage[pos] = lz_hit_record(key, summ) | ((u64)bin << 55);
-            }
-        }
-        __syncthreads();
-        LZ_CLK(7);
-        for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
-            const u64 r = sh.stage[k];
-            const u32 b = (u32)(r >> 55) & 0xFFu;
-            recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = r & ~(0xFFull << 55);
-        }
-        __syncthreads();
-        LZ_CLK(8);
     }
 }
 
-int lzk_probe_part(LzCtx& c, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                   const s32* score_tab, const LzLutEntry* lut, const u32* hist, const u32* part, u64* recs)
+// keys + summaries -> records in their partitions.  One workgroup per tile of k_hist; a wave owns 256 consecutive
+// hits (64 per round), so ranks by (wave, round, lane) follow the discovery order.
+struct LzPartShared {
+    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition (the partition rides in bits 55..62)
+    u32 wcnt[LZ_PP_WAVES][LZ_NBIN];                  // per wave and partition: records / running offset inside the partition
+    u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
+};
+__global__ void __launch_bounds__(LZ_PP_TPB)
+k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
+            const u32* __restrict__ hist, const u32* __restrict__ part, u64* __restrict__ recs)
+{
+    __shared__ LzPartShared sh;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const u32 tile = blockIdx.x;
+    const u64 base = (u64)tile * LZ_PP_TILE;
+    const u32 tile_n = (n - base < (u64)LZ_PP_TILE) ? (u32)(n - base) : (u32)LZ_PP_TILE;
+    for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN; k += LZ_PP_TPB) (&sh.wcnt[0][0])[k] = 0;
+    const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
+    u64 kk[LZ_PP_ROUNDS]; u32 ss[LZ_PP_ROUNDS];
+#pragma unroll
+    for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+        const bool v = l0 + 64u * r < tile_n;
+        kk[r] = v ? keys[base + l0 + 64u * r] : 0ull;
+        ss[r] = v ? summ[base + l0 + 64u * r] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < LZ_PP_ROUNDS; r++) if (l0 + 64u * r < tile_n) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(kk[r])], 1u);
+    __syncthreads();
+    // per-partition counts chained in wave order (= discovery order) ...
+    u32 tot = 0;
+    if (tid < LZ_NBIN) {
+        for (u32 k = 0; k < LZ_PP_WAVES; k++) { const u32 v = sh.wcnt[k][tid]; sh.wcnt[k][tid] = tot; tot += v; }
+        sh.gbase[tid] = part[(size_t)(tile >> 8) * LZ_NBIN + tid] + hist[(size_t)tile * LZ_NBIN + tid];
+    }
+    const u32 ts = lz_exscan256(tot, sh.wtot);
+    if (tid < LZ_NBIN) sh.tstart[tid] = ts;
+    if (tid == 0) sh.tstart[LZ_NBIN] = tile_n;
+    __syncthreads();
+    // ... then every record gets its place: rank among the same-partition lanes of its wave's round, on top of
+    // the wave's running offset (stable: lanes, rounds and waves all follow the discovery order)
+#pragma unroll
+    for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+        const bool valid = l0 + 64u * r < tile_n;
+        const u32 bin = LZ_KEY_BIN(kk[r]);
+        u32 rank, count; bool last;
+        lz_match8(bin, valid, lane, rank, count, last);
+        const u32 old = sh.wcnt[w][bin];
+        if (valid && last) sh.wcnt[w][bin] = old + count;
+        if (valid) sh.stage[sh.tstart[bin] + old + rank] = lz_hit_record(kk[r], ss[r]) | ((u64)bin << 55);
+    }
+    __syncthreads();
+    for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
+        const u64 r = sh.stage[k];
+        const u32 b = (u32)(r >> 55) & 0xFFu;
+        recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = r & ~(0xFFull << 55);
+    }
+}
+
+// grid of k_scan_hits for n hits, and the geometry of its task list: one region per wave, room for 1/8 of the
+// wave's hits + 64 (64 B each; the usual load is ~3 %); a hit that finds its region full is left to phase B
+static void lz_scan_geometry(LzCtx& c, u64 n, u32& grid, u32& n_regions, u32& region_cap)
+{
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
+    static const u32 wgs = getenv("LZGPU_PP_WGS") ? (u32)atoi(getenv("LZGPU_PP_WGS")) : 2u;
+    const u64 nspans = (n + 64u * LZ_PP_ROUNDS - 1) / (64u * LZ_PP_ROUNDS), want = (nspans + LZ_SC_TPB / 64 - 1) / (LZ_SC_TPB / 64);
+    grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
+    n_regions = grid * (LZ_SC_TPB / 64);
+    region_cap = (u32)std::min<u64>(n / 8 / n_regions + 64, 1u << 20);
+}
+// buffers of a set for chunks of up to max_n hits (sized once per search: chunk sizes differ a little, and a
+// device buffer that grows is freed and allocated again)
+int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n)
+{
+    u32 grid, n_regions, region_cap; int rc;
+    lz_scan_geometry(c, max_n, grid, n_regions, region_cap);
+    if ((rc = c.summ[set].ensure((size_t)max_n * 4))) return rc;
+    if (mode < 2 && (rc = c.scan_tasks[set].ensure((size_t)n_regions * region_cap * sizeof(LzScanTask)))) return rc;
+    return c.scan_ntasks[set].ensure((size_t)n_regions * 4);
+}
+
+int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
+                  const s32* score_tab, const LzLutEntry* lut, hipStream_t st)
+{
+    if (n == 0) return 0;
+    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
+    int rc;
+    u32 grid, n_regions, task_cap;
+    lz_scan_geometry(c, n, grid, n_regions, task_cap);
+    if ((rc = c.summ[set].ensure((size_t)n * 4))) return rc;
+    if (mode < 2 && (rc = c.scan_tasks[set].ensure((size_t)n_regions * task_cap * sizeof(LzScanTask)))) return rc;
+    if ((rc = c.scan_ntasks[set].ensure((size_t)n_regions * 4))) return rc;
+    u32* summ = c.summ[set].as<u32>(); LzScanTask* tasks = c.scan_tasks[set].as<LzScanTask>(); u32* ntk = c.scan_ntasks[set].as<u32>();
+    c.timer.begin("k_scan_hits", st);
+    if (mode == 0)      hipLaunchKernelGGL(k_scan_hits<0>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
+    else if (mode == 1) hipLaunchKernelGGL(k_scan_hits<1>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
+    else                hipLaunchKernelGGL(k_scan_hits<2>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
+    c.timer.end(st);
+    LZ_HIP(hipGetLastError());
+    if (mode < 2) {
+        c.timer.begin("k_scan_tasks", st);
+        if (mode == 0) hipLaunchKernelGGL(k_scan_tasks<0>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, tasks, ntk, n_regions, task_cap, summ);
+        else           hipLaunchKernelGGL(k_scan_tasks<1>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, tasks, ntk, n_regions, task_cap, summ);
+        c.timer.end(st);
+        LZ_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, const u32* part, u64* recs, hipStream_t st)
 {
     if (n == 0) return 0;
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE);
-    int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
-    const u32 grid = ntiles < 2u * (u32)cus ? ntiles : 2u * (u32)cus;   // two 512-lane workgroups per CU, each walking its share of the tiles
-    c.timer.begin("k_probe_part", c.stream);
-    if (mode == 0)      hipLaunchKernelGGL(k_probe_part<0>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
-    else if (mode == 1) hipLaunchKernelGGL(k_probe_part<1>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
-    else                hipLaunchKernelGGL(k_probe_part<2>, dim3(grid), dim3(LZ_PP_TPB), 0, c.stream, P, Q, keys, n, ntiles, score_tab, lut, hist, part, recs);
-    c.timer.end(c.stream);
+    c.timer.begin("k_partition", st);
+    hipLaunchKernelGGL(k_partition, dim3(ntiles), dim3(LZ_PP_TPB), 0, st, keys, c.summ[set].as<u32>(), n, hist, part, recs);
+    c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,16 @@
+#!/bin/bash
+# where the wall time of the lastz CLI (GPU-bound binary) goes on the bench pair: host phases of the library
+# (LZGPU_HOSTPROF) and the shim's notes (LZGPU_VERBOSE), two runs (the second has the files in the page cache)
+cd $GRAFT_REPO_ROOT
+python - <<'PY'
+from lastz_amd import seqio
+t, q = seqio.synth_pair(50_000_000, 50_000_000, seed=1000)
+seqio.write_fasta("/tmp/t.fa", [("target", t)]); seqio.write_fasta("/tmp/q.fa", [("query", q)])
+PY
+cd /tmp
+for i in 1 2; do
+  s=$(date +%s.%N)
+  LZGPU_HOSTPROF=1 LZGPU_VERBOSE=1 $GRAFT_REPO_ROOT/oracle/_ref/lastz_gpu t.fa q.fa --ydrop=9430 > /tmp/out.lav 2> /tmp/err.txt
+  e=$(date +%s.%N); python -c "print('run $i wall %.2f s' % ($e - $s))"
+  grep -v "speculates" /tmp/err.txt | tail -60 | cut -c1-200
+done
