@@ -13,6 +13,7 @@
 #include <string.h>
 #include <stdbool.h>
 #include <unistd.h>
+#include <time.h>
 #include "build_options.h"
 #include "utilities.h"
 #include "dna_utilities.h"
@@ -56,6 +57,12 @@ static void note (const char* what, const char* how)
 	{
 	if (shimVerbose < 0) shimVerbose = (getenv ("LZGPU_VERBOSE") != NULL);
 	if (shimVerbose) fprintf (stderr, "[lzgpu] %s: %s\n", what, how);
+	if (getenv ("LZGPU_VERBOSE_CLOCK") != NULL)                  /* where the process's wall time goes (tools/cli_prof.sh) */
+		{
+		struct timespec ts;
+		clock_gettime (CLOCK_MONOTONIC, &ts);
+		fprintf (stderr, "[lzgpu clock] %.3f s (monotonic) after %s: %s\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9, what, how);
+		}
 	}
 
 static void drop_device_table (void) { devTable = NULL;  devTargetV = NULL;  devTargetLen = 0; }

@@ -187,10 +187,14 @@ struct HipDpExec : LzDpExecutor {
         const u64 n = ids.size();
         const u32 row_cap = slot / 16 + 64, ops_cap = slot / 32 + 64;
         int rc;
-        if ((rc = g_dp.tb.ensure((size_t)n * slot))) return rc;
-        if ((rc = g_dp.rows.ensure((size_t)n * row_cap * 4))) return rc;
-        if ((rc = g_dp.ops.ensure((size_t)n * ops_cap * 4))) return rc;
-        if ((rc = g_dp.act.ensure((size_t)n * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
+        // sized for a multiple of 512 DPs: the two strands of a pair launch slightly different numbers of DPs, and a
+        // buffer that grows is freed and allocated again -- 18 GiB of fresh device memory cost the second strand of
+        // the 50 Mbp CLI run a second (tools/cli_prof.sh)
+        const u64 na = (n + 511) / 512 * 512;
+        if ((rc = g_dp.tb.ensure((size_t)na * slot))) return rc;
+        if ((rc = g_dp.rows.ensure((size_t)na * row_cap * 4))) return rc;
+        if ((rc = g_dp.ops.ensure((size_t)na * ops_cap * 4))) return rc;
+        if ((rc = g_dp.act.ensure((size_t)na * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
         for (u64 k = 0; k < n; k++) {
             LzDpJob& J = jobs[ids[k]];
             J.tb_off = k * (u64)slot; J.tb_cap = slot;

@@ -38,6 +38,11 @@ int DevBuf::ensure(size_t bytes)
     if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
     const auto t1 = std::chrono::steady_clock::now();
     size_t want = bytes < 256 ? 256 : bytes;
+    if (want >= (64u << 20)) {                                  // big buffers in steps of 1/16 of their size: a request that
+        size_t step = (size_t)1 << 22;                          // creeps up (the second strand's chunks, a few more DPs) does
+        while (step * 32 <= want) step <<= 1;                   // not free and re-allocate gigabytes
+        want = (want + step - 1) / step * step;
+    }
     hipError_t e = hipMalloc(&p, want);
     if (prof && want >= (64u << 20)) fprintf(stderr, "[lzgpu hostprof] device buffer %zu -> %zu MiB: hipFree %.1f ms, hipMalloc %.1f ms\n", old >> 20, want >> 20,
                                              std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

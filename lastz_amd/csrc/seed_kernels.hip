@@ -888,8 +888,12 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 // tile and the walk checks that the indices ascend (discovery order), sorting the rest of its list when they do
 // not.  A record that needs a real extension (an HSP candidate that passed the diagEnd test) is extended by the
 // lane's whole wave (lz_coop_extend_wave), one such record at a time.
-#define LZ_ST_TPB    1024
+#ifndef LZ_ST_SPLIT
+#define LZ_ST_SPLIT  1                               // workgroups per partition: each reads the whole stream and keeps its share of the buckets
+#endif
+#define LZ_ST_TPB    (1024 / LZ_ST_SPLIT)
 #define LZ_ST_WAVES  (LZ_ST_TPB / 64)
+#define LZ_ST_NB     (LZ_NBIN / LZ_ST_SPLIT)         // buckets of one workgroup
 #define LZ_ST_TILE   4096
 #define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
 #define LZ_ST_BATCH  4
@@ -900,20 +904,21 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
 {
     __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
     __shared__ u64 rec[LZ_ST_TILE + LZ_ST_BATCH];
-    __shared__ u32 cnt[LZ_ST_WAVES][LZ_NBIN];
+    __shared__ u32 cnt[LZ_ST_WAVES][LZ_ST_NB];
     __shared__ u32 wtot[4];
-    __shared__ u32 lbeg[LZ_NBIN], lcnt[LZ_NBIN];
+    __shared__ u32 lbeg[LZ_ST_NB], lcnt[LZ_ST_NB];
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     for (int k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_ST_TPB) tab[k] = score_tab_g[k];
     // The walk is bound by the latency of its short dependent steps, not by lanes: the 256 buckets are spread over
     // all 16 waves (16 lanes each), so that every SIMD has four walking waves to interleave instead of one.
-    const bool walker = lane < (LZ_NBIN / LZ_ST_WAVES);
-    const u32 bucket = lane * LZ_ST_WAVES + w;                  // of a walker lane
-    const u32 h = blockIdx.x * LZ_NBIN + (bucket & (LZ_NBIN - 1));
+    const u32 part = blockIdx.x / LZ_ST_SPLIT, share = blockIdx.x % LZ_ST_SPLIT;   // this workgroup: buckets [share * LZ_ST_NB, +LZ_ST_NB) of partition `part`
+    const bool walker = lane < (LZ_ST_NB / LZ_ST_WAVES);
+    const u32 bucket = lane * LZ_ST_WAVES + w;                  // of a walker lane, inside the share
+    const u32 h = part * LZ_NBIN + share * LZ_ST_NB + (bucket & (LZ_ST_NB - 1));
     const u32 L = P.seed_len;
     u32 dend = walker ? diag_end[h] : 0u;
     u64 n_ext = 0, n_bp = 0;
-    const u32 r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
+    const u32 r0 = bin_base[part], r1 = bin_base[part + 1];
     // a wave owns 512 consecutive records of the tile, which it takes 64 at a time
     u64 x[LZ_ST_ROUNDS];
 #pragma unroll
@@ -921,28 +926,29 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
     for (u32 t0 = r0; t0 < r1; t0 += LZ_ST_TILE) {
         const u32 nt = (r1 - t0 < (u32)LZ_ST_TILE) ? r1 - t0 : (u32)LZ_ST_TILE;
         LZ_CLK_DECL;
-        for (u32 k = tid; k < LZ_ST_WAVES * LZ_NBIN; k += LZ_ST_TPB) (&cnt[0][0])[k] = 0;
+        for (u32 k = tid; k < LZ_ST_WAVES * LZ_ST_NB; k += LZ_ST_TPB) (&cnt[0][0])[k] = 0;
         __syncthreads();
         LZ_CLK(16);
         u32 slot[LZ_ST_ROUNDS];
 #pragma unroll
         for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
             const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
-            slot[rr] = (li < nt) ? atomicAdd(&cnt[w][LZ_REC_LOW8(x[rr])], 1u) : 0u;
+            const u32 b8 = LZ_REC_LOW8(x[rr]);
+            slot[rr] = (li < nt && b8 / LZ_ST_NB == share) ? atomicAdd(&cnt[w][b8 % LZ_ST_NB], 1u) : 0xFFFFFFFFu;    // (0xFFFFFFFF: not this workgroup's)
         }
         __syncthreads();
         LZ_CLK(17);
         // offsets: bucket-major, wave order inside a bucket
         u32 mine = 0;
-        if (tid < LZ_NBIN) for (u32 k = 0; k < LZ_ST_WAVES; k++) { const u32 v = cnt[k][tid]; cnt[k][tid] = mine; mine += v; }
+        if (tid < LZ_ST_NB) for (u32 k = 0; k < LZ_ST_WAVES; k++) { const u32 v = cnt[k][tid]; cnt[k][tid] = mine; mine += v; }
         const u32 beg = lz_exscan256(mine, wtot);
-        if (tid < LZ_NBIN) { for (u32 k = 0; k < LZ_ST_WAVES; k++) cnt[k][tid] += beg; lbeg[tid] = beg; lcnt[tid] = mine; }
+        if (tid < LZ_ST_NB) { for (u32 k = 0; k < LZ_ST_WAVES; k++) cnt[k][tid] += beg; lbeg[tid] = beg; lcnt[tid] = mine; }
         __syncthreads();
         LZ_CLK(18);
 #pragma unroll
         for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
             const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
-            if (li < nt) rec[cnt[w][LZ_REC_LOW8(x[rr])] + slot[rr]] = lz_rec_with_index(x[rr], li);
+            if (slot[rr] != 0xFFFFFFFFu) rec[cnt[w][LZ_REC_LOW8(x[rr]) % LZ_ST_NB] + slot[rr]] = lz_rec_with_index(x[rr], li);
         }
         __syncthreads();
         LZ_CLK(19);
@@ -1002,7 +1008,7 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
                     const int src = (int)__ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const u32 sp2 = (u32)__shfl((int)pp2, src), spay = (u32)__shfl((int)ppay, src), sdend = (u32)__shfl((int)dend, src);
-                    const u32 sh_ = blockIdx.x * LZ_NBIN + (u32)src * LZ_ST_WAVES + w;
+                    const u32 sh_ = part * LZ_NBIN + share * LZ_ST_NB + (u32)src * LZ_ST_WAVES + w;
                     const s32 diag = (s32)((spay << 16) | sh_);
                     const u32 pos1 = sp2 + (u32)diag;
                     s32 stopl = (s32)sdend + diag;  if (stopl < 0) stopl = 0;                                     // :2612-2616
@@ -1046,7 +1052,7 @@ int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bi
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
     c.timer.begin("k_settle", s);
-    hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
+    hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN * LZ_ST_SPLIT), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
