@@ -115,7 +115,9 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 struct LzLutParams; struct LzLutEntry;
-#define LZ_PP_TILE_HOST 2048        // hits per tile of k_hist / k_probe_part (sizes the partition histogram)
+#ifndef LZ_PP_TILE_HOST
+#define LZ_PP_TILE_HOST 8192        // hits per tile of k_hist / k_partition (sizes the partition histogram)
+#endif
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
 int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);

@@ -470,10 +470,15 @@ void lz_phase_clocks_print()
 #define LZ_CLK(slot)
 void lz_phase_clocks_print() {}
 #endif
+#ifndef LZ_PP_TPB
 #define LZ_PP_TPB    512
+#endif
 #define LZ_PP_WAVES  (LZ_PP_TPB / 64)
-#define LZ_PP_ROUNDS 4
-#define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile
+#define LZ_SC_ROUNDS 4                               // k_scan_hits: rounds of 64 hits a wave takes per span
+#ifndef LZ_PP_ROUNDS
+#define LZ_PP_ROUNDS (LZ_PP_TILE_HOST / LZ_PP_TPB)   // k_partition: records per lane
+#endif
+#define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile of k_hist / k_partition
 #define LZ_PP_QCAP   96                              // unfinished scans a tile can queue (beyond that the hit is left to phase B)
 #define LZ_NBIN      256
 #define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // bits 8..15 of hashedDiag
@@ -600,7 +605,7 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
     const LzLutEntry* lut = sh.lut;
     constexpr bool SP = MODE == 1;
     constexpr bool HLIM = SP;                        // MODE 0 heads run without limit tests: a side with less than 60 bases of room becomes a task
-    constexpr u32 SPAN = 64u * LZ_PP_ROUNDS;
+    constexpr u32 SPAN = 64u * LZ_SC_ROUNDS;
     const u64 nspans = (n + SPAN - 1) / SPAN, wstride = (u64)gridDim.x * (LZ_SC_TPB / 64);
     // the tasks of a wave go to the wave's own region of the list: no atomics, the count is written once at the end
     const u32 region = blockIdx.x * (LZ_SC_TPB / 64) + w;
@@ -614,7 +619,7 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
         k2 = (lane + 128u < span_n) ? keys[base + lane + 128u] : 0ull; k3 = (lane + 192u < span_n) ? keys[base + lane + 192u] : 0ull;
         if (MODE == 2) {
 #pragma unroll 1
-            for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+            for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
                 const u32 li = r * 64u + lane;
                 if (li < span_n) summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, k0);
                 const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
@@ -624,13 +629,13 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
             lz_lut_init(k0, P.tlen, P.qlen, diag, L, R);
             lz_lut_fetch<false, SP>(Q, L.s, diag, rawl); lz_lut_fetch<true, SP>(Q, R.s, diag, rawr);
 #pragma unroll 1
-            for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+            for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
                 const u32 li = r * 64u + lane;
                 const bool valid = li < span_n;
                 // the next round's windows
                 s32 ndiag; LzLutScan NL, NR; LzLutRaw<SP> nrawl, nrawr;
                 lz_lut_init(k1, P.tlen, P.qlen, ndiag, NL, NR);
-                if (r + 1 < LZ_PP_ROUNDS) { lz_lut_fetch<false, SP>(Q, NL.s, ndiag, nrawl); lz_lut_fetch<true, SP>(Q, NR.s, ndiag, nrawr); }
+                if (r + 1 < LZ_SC_ROUNDS) { lz_lut_fetch<false, SP>(Q, NL.s, ndiag, nrawl); lz_lut_fetch<true, SP>(Q, NR.s, ndiag, nrawr); }
                 else { nrawl = rawl; nrawr = rawr; }
                 if (!valid) { L.alive = 0; R.alive = 0; }
                 const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
@@ -741,7 +746,7 @@ static void lz_scan_geometry(LzCtx& c, u64 n, u32& grid, u32& n_regions, u32& re
 {
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
     static const u32 wgs = getenv("LZGPU_PP_WGS") ? (u32)atoi(getenv("LZGPU_PP_WGS")) : 2u;
-    const u64 nspans = (n + 64u * LZ_PP_ROUNDS - 1) / (64u * LZ_PP_ROUNDS), want = (nspans + LZ_SC_TPB / 64 - 1) / (LZ_SC_TPB / 64);
+    const u64 nspans = (n + 64u * LZ_SC_ROUNDS - 1) / (64u * LZ_SC_ROUNDS), want = (nspans + LZ_SC_TPB / 64 - 1) / (LZ_SC_TPB / 64);
     grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
     n_regions = grid * (LZ_SC_TPB / 64);
     region_cap = (u32)std::min<u64>(n / 8 / n_regions + 64, 1u << 20);
@@ -894,7 +899,9 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 #define LZ_ST_TPB    (1024 / LZ_ST_SPLIT)
 #define LZ_ST_WAVES  (LZ_ST_TPB / 64)
 #define LZ_ST_NB     (LZ_NBIN / LZ_ST_SPLIT)         // buckets of one workgroup
+#ifndef LZ_ST_TILE
 #define LZ_ST_TILE   4096
+#endif
 #define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
 #define LZ_ST_BATCH  4
 __global__ void __launch_bounds__(LZ_ST_TPB)
