@@ -364,9 +364,38 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
                 if ((int)p >= d) incl += v;
             }
             const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
-            u64* o = out + carry + (incl - len);
-            if (OWNED) { for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) *o++ = lz_hit_key(p1, pos2); } }
-            else for (u32 jj = 0; jj < len; jj++) o[jj] = lz_hit_key(wpos[a + jj], pos2);
+            if (OWNED) {
+                u64* o = out + carry + (incl - len);
+                for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) *o++ = lz_hit_key(p1, pos2); }
+            } else {
+                // The (up to) 64 lists of the wave -- 4 positions x 16 probes -- laid end to end: lane t takes hit t,
+                // t + 64, ... of that run, finds the list holding it (binary search over the lanes' running totals)
+                // and writes it to its place: the stores of a wave are consecutive keys (one run per position),
+                // not one 8-byte store per list and step.
+                u32 gtot = total;                             // running totals over the whole wave: + the groups below
+                const u32 t0 = __shfl(total, 0), t1 = __shfl(total, 16), t2 = __shfl(total, 32), t3 = __shfl(total, 48);
+                const u32 gbase = g == 0 ? 0u : g == 1 ? t0 : g == 2 ? t0 + t1 : t0 + t1 + t2;      // hits of the groups below this lane's
+                gtot = t0 + t1 + t2 + t3;
+                const u32 winc = gbase + incl;                // inclusive running total at this lane
+                const s64 obase = have ? (s64)(out - keys) + (s64)carry - (s64)gbase : 0;           // key index of the group's run, minus gbase
+                for (u32 tb = 0; tb < gtot; tb += 64u) {      // wave-uniform trips: every lane takes part in the shuffles
+                    const u32 t = tb + lane;
+                    u32 lo_l = 0, hi_l = 63;                  // first lane whose inclusive total exceeds t
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const u32 mid = (lo_l + hi_l) >> 1;
+                        const u32 v = (u32)__shfl((int)winc, (int)mid);
+                        if (v > t) hi_l = mid; else lo_l = mid + 1;
+                    }
+                    const u32 L = lo_l;
+                    const u32 l_inc = (u32)__shfl((int)winc, (int)L), l_len = (u32)__shfl((int)len, (int)L), l_a = (u32)__shfl((int)a, (int)L);
+                    const u32 l_pos2 = (u32)__shfl((int)pos2, (int)L);
+                    const u32 ob_lo = (u32)__shfl((int)(u32)obase, (int)L), ob_hi = (u32)__shfl((int)(u32)((u64)obase >> 32), (int)L);
+                    const u32 jj = t - (l_inc - l_len);
+                    const s64 ob = (s64)(((u64)ob_hi << 32) | ob_lo);
+                    if (t < gtot) keys[ob + (s64)t] = lz_hit_key(wpos[l_a + jj], l_pos2);
+                }
+            }
             carry += total;
         }
     }
