@@ -271,6 +271,30 @@ def test_two_mbp_pair_and_capacity_invariance(gpu):
         assert (a == b).all()
 
 
+def test_three_stream_chunk_pipeline(gpu, tmp_path):
+    """LZGPU_OVERLAP=1 (fill + histogram | scans | partition, phase B behind the next chunk's scans, three buffer
+    sets) gives the same HSP list as the one-stream default: many small chunks, both strands, fresh process."""
+    t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=12)
+    _, masked = H.scoring()
+    _prep(gpu, t)
+    want = [gpu.seed_hit_search(masked, q=qq) for _, _, qq in H.strands(q)]
+    np.save(tmp_path / "want0.npy", want[0]); np.save(tmp_path / "want1.npy", want[1])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from lastz_amd import seqio, lzgpu; import helpers as H; from oracle import lzo\n"
+            "g = lzgpu.Lib(); g.init()\n"
+            "t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=12); _, masked = H.scoring()\n"
+            "g.table_prepare(t, g.seed(H.DEFAULT_SEED, 1), lzo.upper_nuc_to_bits())\n"
+            "for cap in (150000, 700000):\n"
+            "    g.set_hit_capacity(cap)\n"
+            "    for k, (_, _, qq) in enumerate(H.strands(q)):\n"
+            "        got = g.seed_hit_search(masked, q=qq); want = np.load(%r %% k)\n"
+            "        assert len(got) == len(want) and (got == want).all(), (cap, k)\n"
+            "print('pipeline ok')\n" % (H.ROOT, os.path.join(H.ROOT, "tests"), str(tmp_path / "want%d.npy")))
+    env = dict(os.environ); env["LZGPU_OVERLAP"] = "1"; env.pop("LZGPU_SERIAL", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "pipeline ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_full_size_properties(gpu):
     """BASELINE.json configs[1] size (50 Mbp x 50 Mbp, one strand): properties that do not
     need the oracle -- determinism, chunk-capacity invariance, every HSP re-scores to its score on
