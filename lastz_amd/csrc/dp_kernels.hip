@@ -229,13 +229,15 @@ struct HipDpExec : LzDpExecutor {
         c.timer.resolve();
         for (u32 id : ids) res[id] = all[id];
         if (getenv("LZGPU_DPPROF")) {
-            u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0; u64 ph[4] = { 0, 0, 0, 0 };
+            u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0; u64 ph[4] = { 0, 0, 0, 0 }, ld[5] = { 0, 0, 0, 0, 0 };
             for (u32 id : ids) { sum_r += all[id].t_rows; sum_t += all[id].t_trace;
-                                 if (all[id].t_rows + all[id].t_trace > mr) { for (int q = 0; q < 4; q++) ph[q] = all[id].t_ph[q]; mr = all[id].t_rows + all[id].t_trace; tr = all[id].t_rows; tt = all[id].t_trace; rows = all[id].max_row; cells = all[id].cells; } }
+                                 if (all[id].t_rows + all[id].t_trace > mr) { for (int q = 0; q < 4; q++) ph[q] = all[id].t_ph[q]; for (int q = 0; q < 5; q++) ld[q] = all[id].t_ld[q]; mr = all[id].t_rows + all[id].t_trace; tr = all[id].t_rows; tt = all[id].t_trace; rows = all[id].max_row; cells = all[id].cells; } }
             fprintf(stderr, "[lzgpu dpprof] launch of %zu DPs: longest = %u rows, %llu cells, sweep %llu ticks (%.0f/row), traceback %llu ticks; all DPs: sweep %llu, traceback %llu ticks; longest by step: lane0 %llu, walk1+scan %llu, walk2+scan %llu, walk3+reduce %llu\n",
                     ids.size(), rows, (unsigned long long)cells, (unsigned long long)tr, rows ? (double)tr / rows : 0.0, (unsigned long long)tt,
                     (unsigned long long)sum_r, (unsigned long long)sum_t,
                     (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3]);
+            if (ld[0] + ld[1] + ld[2] + ld[3] + ld[4]) fprintf(stderr, "[lzgpu dpprof]   lane-0 step of the longest, per row: row results %.0f, row end %.0f, bounds %.0f, active segments %.0f, budget + publish %.0f ticks\n",
+                    rows ? (double)ld[0] / rows : 0.0, rows ? (double)ld[1] / rows : 0.0, rows ? (double)ld[2] / rows : 0.0, rows ? (double)ld[3] / rows : 0.0, rows ? (double)ld[4] / rows : 0.0);
         }
         return 0;
     }

@@ -79,6 +79,7 @@ struct LzDpResult {
     u32 tb_used; u64 cells;
     u64 t_rows, t_trace;                // shader-clock ticks spent in the row sweep / the traceback (0 off-device)
     u64 t_ph[4];                        // ... of which: lane-0 step, walk 1 + gap scan, walk 2 + best scan, walk 3 + reduce
+    u64 t_ld[5];                        // the lane-0 step, split (leading wave only): row results, row end, bounds, active segments, budget + publish
 };
 
 struct LzDpParams {                     // per batch
@@ -349,7 +350,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
             if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
-                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; for (int q = 0; q < 4; q++) res->t_ph[q] = 0; } });
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; for (int q = 0; q < 4; q++) res->t_ph[q] = 0; for (int q = 0; q < 5; q++) res->t_ld[q] = 0; } });
         return;
     }
 
@@ -407,9 +408,11 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     u32 row = 0, LY0 = 0, RYi = 0, cpl = 0, trow_cur = 0; s32 best0 = 0, i_last = 0;     // of the row in flight (uniform)
     bool swept = false;
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
+    u64 tl[5] = { 0, 0, 0, 0, 0 };
     while (!sh.done) {
         const u64 ts = LZ_PHASE_CLOCK();
         x.leader([&]() {
+            u64 q0 = LZ_PHASE_CLOCK(), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
             [&]() {
             u32 extra = 0;
             if (swept) {
@@ -417,6 +420,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 u32 first, last, ccol; s32 cmax;
                 x.row_result(sh, first, last, cmax, ccol);
                 first = x.uni(first); last = x.uni(last); cmax = x.uni(cmax); ccol = x.uni(ccol);
+                q1 = LZ_PHASE_CLOCK();
                 const u32 iter = RYi - LY0;
                 ct.cells += iter;
                 u32 tb_used = ct.tb_used + iter;
@@ -456,12 +460,15 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 if (sh.stage_a) extra = 1;
             }
             sh.extra = extra;
+            q2 = LZ_PHASE_CLOCK();
             // set-up of the next row: bounds, active segments, traceback budget
             if (ct.row >= M) { ct.done = 1; return; }
             ct.row++;
             ct.prevLY = ct.LY;
             lz_dp_update_lr(x, S, ct, J);
+            q3 = LZ_PHASE_CLOCK();
             lz_dp_update_active(x, S, sh, ct, J, P.act_arena + J.act_off);
+            q4 = LZ_PHASE_CLOCK();
             if (ct.done) return;
             if (ct.RY < ct.LY) ct.RY = ct.LY;                   // note 11
             const u32 width = ct.RY - ct.LY;
@@ -475,6 +482,9 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
             }();
             sh.done = ct.done; sh.row = ct.row; sh.LY = ct.LY; sh.best = ct.best; sh.n_act = ct.n_act; sh.b_hi = ct.b_hi;
+            const u64 q5 = LZ_PHASE_CLOCK();
+            if (q1 < q0) q1 = q0; if (q2 < q1) q2 = q1; if (q3 < q2) q3 = q2; if (q4 < q3) q4 = q3;
+            tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += q5 - q4;
         });
         if (sh.done) break;
         if (sh.extra) x.phase([&](int lane, LzDpLane&) {
@@ -677,5 +687,6 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         res->tb_used = ct.tb_used; res->cells = ct.cells;
         res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
         res->t_ph[0] = tp0; res->t_ph[1] = tp1; res->t_ph[2] = tp2; res->t_ph[3] = tp3;
+        for (int q = 0; q < 5; q++) res->t_ld[q] = tl[q];
     });
 }
