@@ -236,6 +236,15 @@ struct HipDpExec : LzDpExecutor {
                     ids.size(), rows, (unsigned long long)cells, (unsigned long long)tr, rows ? (double)tr / rows : 0.0, (unsigned long long)tt,
                     (unsigned long long)sum_r, (unsigned long long)sum_t,
                     (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3]);
+            {   // where in the launch the longest DP ran (100 MHz clock common to all CUs), relative to the first start
+                u64 base = ~0ull, last_end = 0, lb = 0, le = 0; size_t pos = 0, lpos = 0, late = 0;
+                for (u32 id : ids) { if (all[id].t_begin && all[id].t_begin < base) base = all[id].t_begin; }
+                for (u32 id : ids) { if (all[id].t_end > last_end) last_end = all[id].t_end;
+                                     if (all[id].t_begin > base + 100000) late++;               // started more than 1 ms after the first
+                                     if (all[id].t_rows + all[id].t_trace == mr) { lb = all[id].t_begin; le = all[id].t_end; lpos = pos; } pos++; }
+                if (base != ~0ull) fprintf(stderr, "[lzgpu dpprof]   longest DP is job %zu of %zu: runs %.2f .. %.2f ms after the first start; the last DP ends at %.2f ms; %zu DPs started more than 1 ms late\n",
+                                           lpos, ids.size(), (lb - base) * 1e-5, (le - base) * 1e-5, (last_end - base) * 1e-5, late);
+            }
             if (ld[0] + ld[1] + ld[2] + ld[3] + ld[4]) fprintf(stderr, "[lzgpu dpprof]   lane-0 step of the longest, per row: row results %.0f, row end %.0f, bounds %.0f, active segments %.0f, budget + publish %.0f ticks\n",
                     rows ? (double)ld[0] / rows : 0.0, rows ? (double)ld[1] / rows : 0.0, rows ? (double)ld[2] / rows : 0.0, rows ? (double)ld[3] / rows : 0.0, rows ? (double)ld[4] / rows : 0.0);
         }
@@ -294,6 +303,10 @@ struct HipDpExec : LzDpExecutor {
         // ---- first try: every job in a small slot; then the (rare) overflows in growing slots
         std::vector<u32> ids(jobs.size()), wide_ids;
         for (u32 k = 0; k < jobs.size(); k++) ids[k] = k;
+        // blocks are dispatched in index order and a CU holds four DPs: the DPs expected to sweep the most rows go
+        // first (est_rows, lz_gapped_host.cpp), so that the launch does not end on a long DP that started late
+        if (!getenv("LZGPU_DP_NO_ORDER"))
+            std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return jobs[a].est_rows > jobs[b].est_rows; });
         u32 slot = slot_tb;
         while (!ids.empty() || !wide_ids.empty()) {
             // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch

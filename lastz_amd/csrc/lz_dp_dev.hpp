@@ -71,6 +71,7 @@ struct LzDpJob {
     u64 row_off; u32 row_cap;           // tbRow[] slot (u32 per row)
     u64 ops_off; u32 ops_cap;           // edit ops slot (u32 each, traceback order)
     u64 act_off;                        // overflow slot of the active-segment list (LZ_DP_MAXACT - LZ_DP_ACT_LDS entries)
+    u32 est_rows;                       // host-side guess of how many rows this DP will sweep (launch order only: longest first)
 };
 
 struct LzDpResult {
@@ -78,6 +79,7 @@ struct LzDpResult {
     u32 max_row, min_col, max_col;      // explored region in DP coordinates (row 0..max_row)
     u32 tb_used; u64 cells;
     u64 t_rows, t_trace;                // shader-clock ticks spent in the row sweep / the traceback (0 off-device)
+    u64 t_begin, t_end;                 // constant 100 MHz clock (s_memrealtime, the same on every CU) when the DP started / ended (LZGPU_DPPROF)
     u64 t_ph[4];                        // ... of which: lane-0 step, walk 1 + gap scan, walk 2 + best scan, walk 3 + reduce
     u64 t_ld[5];                        // the lane-0 step, split (leading wave only): row results, row end, bounds, active segments, budget + publish
 };
@@ -180,8 +182,10 @@ LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ_CLOCK() ((u64)__builtin_readcyclecounter())
+#define LZ_REALTIME() ((u64)__builtin_amdgcn_s_memrealtime())
 #else
 #define LZ_CLOCK() ((u64)0)
+#define LZ_REALTIME() ((u64)0)
 #endif
 // per-row step clocks (t_ph[], LZGPU_DPPROF): four s_memtime reads per row cost ~2-3 % of the sweep, so they
 // are compiled in only with -DLZ_DP_PHASE_CLOCKS; the two per-DP totals are always taken
@@ -350,11 +354,12 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
             if (lane == 0) { res->score = 0; res->end1 = res->end2 = 0; res->n_ops = 0; res->status = LZ_DP_OK; res->truncated = 0;
-                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; for (int q = 0; q < 4; q++) res->t_ph[q] = 0; for (int q = 0; q < 5; q++) res->t_ld[q] = 0; } });
+                             res->max_row = res->min_col = res->max_col = 0; res->tb_used = 0; res->cells = 0; res->t_rows = res->t_trace = 0; res->t_begin = res->t_end = 0; for (int q = 0; q < 4; q++) res->t_ph[q] = 0; for (int q = 0; q < 5; q++) res->t_ld[q] = 0; } });
         return;
     }
 
     const u64 t0 = LZ_CLOCK();
+    const u64 rt0 = LZ_REALTIME();
     LzDpCtl ct;                                                 // lane 0's
     // ---- set-up + row 0 (:3500-3605)
     x.leader([&]() {
@@ -685,7 +690,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         res->status = ct.status; res->truncated = ct.truncated;
         res->max_row = ct.max_row; res->min_col = ct.min_col; res->max_col = ct.max_col;
         res->tb_used = ct.tb_used; res->cells = ct.cells;
-        res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1;
+        res->t_rows = t1 - t0; res->t_trace = LZ_CLOCK() - t1; res->t_begin = rt0; res->t_end = LZ_REALTIME();
         res->t_ph[0] = tp0; res->t_ph[1] = tp1; res->t_ph[2] = tp2; res->t_ph[3] = tp3;
         for (int q = 0; q < 5; q++) res->t_ld[q] = tl[q];
     });

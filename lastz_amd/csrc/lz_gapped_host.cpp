@@ -369,10 +369,16 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::unordered_map<u32, Cached> cache;
     std::vector<Entry> entries;
     std::vector<u32> fresh;                                    // anchors launched in this round
-    std::unordered_map<s64, std::vector<std::pair<s64, s64>>> chosen_grid;   // (diag, pos1) of selected anchors, this window
+    struct Chosen { s64 dg, a1; u32 ext; };                    // a selected anchor of this window, and its slot in ext_l / ext_r
+    std::unordered_map<s64, std::vector<Chosen>> chosen_grid;
+    // How far the deferred anchors near a selected one reach on either side of it: a guess at the rows its two DPs
+    // will sweep (the anchors an alignment swallows line up along it).  Only the launch order uses it -- a launch
+    // lasts as long as its longest DP, so the long ones should be among the first resident.
+    std::vector<u32> ext_l, ext_r;
+    std::unordered_map<u32, u32> ext_of;                       // anchor index -> slot
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        jobs.clear(); entries.clear(); chosen_grid.clear(); fresh.clear();
+        jobs.clear(); entries.clear(); chosen_grid.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear();
         u32 insured = 0;
         u32 j = next;
         const u32 scan_limit = 64 * W;
@@ -395,9 +401,11 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                     auto g = chosen_grid.find(cc);
                     if (g == chosen_grid.end()) continue;
                     for (auto& c : g->second)
-                        if (c.first - dg <= NEAR_DIAG && dg - c.first <= NEAR_DIAG &&
-                            c.second - (s64)a1 <= NEAR_POS && (s64)a1 - c.second <= NEAR_POS) {
-                            near = (c.first - dg <= TIGHT_DIAG && dg - c.first <= TIGHT_DIAG) ? 2 : (near < 1 ? 1 : near);
+                        if (c.dg - dg <= NEAR_DIAG && dg - c.dg <= NEAR_DIAG &&
+                            c.a1 - (s64)a1 <= NEAR_POS && (s64)a1 - c.a1 <= NEAR_POS) {
+                            near = (c.dg - dg <= TIGHT_DIAG && dg - c.dg <= TIGHT_DIAG) ? 2 : (near < 1 ? 1 : near);
+                            if ((s64)a1 < c.a1) { const u32 d = (u32)(c.a1 - (s64)a1); if (d > ext_l[c.ext]) ext_l[c.ext] = d; }
+                            else                { const u32 d = (u32)((s64)a1 - c.a1); if (d > ext_r[c.ext]) ext_r[c.ext] = d; }
                             if (near == 2) break;
                         }
                 }
@@ -406,7 +414,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 if (near == 1 && insured < INSURE) { insured++; near = 0; }
                 if (near) { entries.push_back({ j, false }); continue; }
             }
-            chosen_grid[cell].push_back({ dg, (s64)a1 });
+            ext_of[j] = (u32)ext_l.size();
+            chosen_grid[cell].push_back({ dg, (s64)a1, (u32)ext_l.size() });
+            ext_l.push_back(0); ext_r.push_back(0);
             entries.push_back({ j, true });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
@@ -431,6 +441,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         lap(t_window);
         if (prof && st.rounds >= 1) { fprintf(stderr, "[lzgpu hostprof] round %u speculates anchors (rank:score):", (unsigned)st.rounds + 1); for (size_t k = 0; k < fresh.size() && k < 12; k++) fprintf(stderr, " %u:%d", fresh[k], anchors[fresh[k]].s); fprintf(stderr, " of %u entries\n", (unsigned)entries.size()); }
         if (entries.empty()) { next = j; break; }
+        for (size_t k = 0; k < fresh.size(); k++) {            // (the extents kept growing while the window was scanned)
+            const u32 e = ext_of[fresh[k]];
+            jobs[2 * k].est_rows = ext_l[e]; jobs[2 * k + 1].est_rows = ext_r[e];
+        }
         if (!jobs.empty()) {
             res.assign(jobs.size(), LzDpResult());
             ops.assign(jobs.size(), std::vector<u32>());
