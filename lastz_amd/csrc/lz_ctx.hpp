@@ -74,6 +74,7 @@ struct LzCtx {
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
     DevBuf wiv, wsk, wsv;           // position index; (word, position) sorted by word
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
+    DevBuf bins[LZ_SETS];           // the partition (high hash byte) of every hit of the chunk, written beside the keys
     DevBuf keys[LZ_SETS];                 // hit keys of a chunk, discovery order (two sets of every per-chunk buffer: the chunk pipeline)
     DevBuf recs[LZ_SETS], bin_base[LZ_SETS];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
                                     // phase B of a chunk runs while the next chunk is filled / scanned / partitioned
@@ -111,7 +112,7 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);   // honours c.n_owners / c.owner
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out);
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st);
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 struct LzLutParams; struct LzLutEntry;
@@ -119,7 +120,7 @@ struct LzLutParams; struct LzLutEntry;
 #define LZ_PP_TILE_HOST 8192        // hits per tile of k_hist / k_partition (sizes the partition histogram)
 #endif
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
-int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
+int lzk_hist(LzCtx& c, const u8* bins, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);
 int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
                   const s32* score_tab, const LzLutEntry* lut, hipStream_t st);     // -> c.summ[set]

@@ -31,7 +31,9 @@
 #pragma once
 #include "lz_common.hpp"
 
+#ifndef LZ_DP_LANES
 #define LZ_DP_LANES   256             // lanes (threads) per one-sided DP: 4 waves of one workgroup
+#endif
 #define LZ_DP_WAVES   (LZ_DP_LANES / 64)
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
 #define LZ_DP_WIDEW   65536           // ... of the wide variant, whose ring lives in HBM (bands the LDS ring cannot hold)

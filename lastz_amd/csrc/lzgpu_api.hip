@@ -170,7 +170,7 @@ extern "C" void lzgpu_shutdown(void)
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
                        &c.dev_counters, &c.tb_keys, &c.tb_vals, &c.tb_keys2, &c.tb_vals2 };
     for (DevBuf* b : bufs) b->release();
-    for (int k = 0; k < LZ_SETS; k++) { DevBuf* sb[] = { &c.keys[k], &c.recs[k], &c.bin_base[k], &c.hist[k], &c.hist_part[k], &c.summ[k], &c.scan_tasks[k], &c.scan_ntasks[k] }; for (DevBuf* b : sb) b->release(); }
+    for (int k = 0; k < LZ_SETS; k++) { DevBuf* sb[] = { &c.bins[k], &c.keys[k], &c.recs[k], &c.bin_base[k], &c.hist[k], &c.hist_part[k], &c.summ[k], &c.scan_tasks[k], &c.scan_ntasks[k] }; for (DevBuf* b : sb) b->release(); }
     for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); kv.second.two.release(); kv.second.spc.release(); kv.second.occ_dev.release(); }
     c.target.dp.release(); c.target.nib.release(); c.target.two.release(); c.target.spc.release(); c.target.occ_dev.release();
     lz_release_statics();
@@ -537,6 +537,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
             const size_t ntiles = (size_t)((max_chunk + LZ_PP_TILE_HOST - 1) / LZ_PP_TILE_HOST), nblocks = (ntiles + 255) / 256;
             for (int k = 0; k < nsets; k++) {
                 if ((rc = c.keys[k].ensure((size_t)max_chunk * 8))) return rc;
+                if ((rc = c.bins[k].ensure((size_t)max_chunk + 64))) return rc;
                 if ((rc = c.recs[k].ensure((size_t)max_chunk * 8))) return rc;
                 if ((rc = c.bin_base[k].ensure(257 * 4))) return rc;
                 if ((rc = c.hist[k].ensure(ntiles * 256 * 4))) return rc;
@@ -613,7 +614,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     for (auto& ch : chunks) {
         const int set = (int)(ci % (size_t)nsets);
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
-            if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[0].as<u64>(), sF))) return rc;
+            if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[0].as<u64>(), c.bins[0].as<u8>(), sF))) return rc;
             std::vector<u64> hk(ch.nh);
             LZ_HIP(hipMemcpyAsync(hk.data(), c.keys[0].p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));
             LZ_HIP(hipStreamSynchronize(c.stream));
@@ -624,8 +625,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (reuse && pending == set) { if ((rc = settle(pending))) return rc; pending = -1; }   // (fewer than three sets)
         // F: keys + histogram (every buffer of the set is free once its phase B is done)
         if (reuse) LZ_HIP(hipStreamWaitEvent(sF, c.ev_extended[set], 0));
-        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[set].as<u64>(), sF))) return rc;
-        if ((rc = lzk_hist(c, c.keys[set].as<u64>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.bin_base[set].as<u32>(), sF))) return rc;
+        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[set].as<u64>(), c.bins[set].as<u8>(), sF))) return rc;
+        if ((rc = lzk_hist(c, c.bins[set].as<u8>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.bin_base[set].as<u32>(), sF))) return rc;
         LZ_HIP(hipEventRecord(c.ev_keys[set], sF));
         // S: the scans
         LZ_HIP(hipStreamWaitEvent(sS, c.ev_keys[set], 0));

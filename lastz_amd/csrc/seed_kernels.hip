@@ -320,13 +320,14 @@ int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stri
 // probe (exact word / transition flip) per lane.  Each lane reads its word's CSR range, a 16-lane prefix
 // sum places the probes' lists back to back in probe order (= the reference's enumeration order within a
 // position, src/seed_search.c:522-549), and the lists go to off[position] in the hit array.
+#define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // the partition of a hit: bits 8..15 of hashedDiag
 #define LZ_FILL_GROUP 16
 template <bool OWNED>
 __global__ void __launch_bounds__(LZ_TPB)
 k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
             const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
-            u64 base, u64* __restrict__ keys, u32 n_owners, u32 owner)
+            u64 base, u64* __restrict__ keys, u8* __restrict__ bins, u32 n_owners, u32 owner)
 {
     const u32 lane = threadIdx.x & 63u, p = lane & (LZ_FILL_GROUP - 1), g = lane >> 4;
     const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane
@@ -366,7 +367,7 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
             if (OWNED) {
                 u64* o = out + carry + (incl - len);
-                for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) *o++ = lz_hit_key(p1, pos2); }
+                for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) { const u64 kk = lz_hit_key(p1, pos2); bins[o - keys] = (u8)LZ_KEY_BIN(kk); *o++ = kk; } }
             } else {
                 // The (up to) 64 lists of the wave -- 4 positions x 16 probes -- laid end to end: lane t takes hit t,
                 // t + 64, ... of that run, finds the list holding it (binary search over the lanes' running totals)
@@ -393,7 +394,7 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
                     const u32 ob_lo = (u32)__shfl((int)(u32)obase, (int)L), ob_hi = (u32)__shfl((int)(u32)((u64)obase >> 32), (int)L);
                     const u32 jj = t - (l_inc - l_len);
                     const s64 ob = (s64)(((u64)ob_hi << 32) | ob_lo);
-                    if (t < gtot) keys[ob + (s64)t] = lz_hit_key(wpos[l_a + jj], l_pos2);
+                    if (t < gtot) { const u64 kk = lz_hit_key(wpos[l_a + jj], l_pos2); keys[ob + (s64)t] = kk; bins[ob + (s64)t] = (u8)LZ_KEY_BIN(kk); }    // (the partition of every hit, one byte: k_hist reads these instead of the keys)
                 }
             }
             carry += total;
@@ -401,16 +402,16 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
     }
 }
 
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st)
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st)
 {
     if (n == 0 || i1 <= i0) return 0;
     c.timer.begin("k_fill_hits", st);
     if (c.n_owners > 1)
         hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, c.n_owners, c.owner);
+                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, c.n_owners, c.owner);
     else
         hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, 1u, 0u);
+                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, 1u, 0u);
     c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -510,20 +511,23 @@ void lz_phase_clocks_print() {}
 #define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile of k_hist / k_partition
 #define LZ_PP_QCAP   96                              // unfinished scans a tile can queue (beyond that the hit is left to phase B)
 #define LZ_NBIN      256
-#define LZ_KEY_BIN(k)  ((u32)((k) >> 40) & 0xFFu)    // bits 8..15 of hashedDiag
 
 // hist[tile][bin]: hits of the tile per partition
 __global__ void __launch_bounds__(LZ_TPB)
-k_hist(const u64* __restrict__ keys, u64 n, u32* __restrict__ hist)
+k_hist(const u8* __restrict__ bins, u64 n, u32* __restrict__ hist)
 {
     __shared__ u32 cnt[LZ_NBIN];
     cnt[threadIdx.x] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * LZ_PP_TILE;
 #pragma unroll
-    for (int r = 0; r < LZ_PP_TILE / LZ_TPB; r++) {
-        const u64 i = base + (u64)r * LZ_TPB + threadIdx.x;
-        if (i < n) atomicAdd(&cnt[LZ_KEY_BIN(keys[i])], 1u);
+    for (int r = 0; r < LZ_PP_TILE / (LZ_TPB * 16); r++) {      // 16 partition bytes per lane and step
+        const u64 i = base + ((u64)r * LZ_TPB + threadIdx.x) * 16u;
+        if (i < n) {
+            const LzVec16 v = lz_load16(bins + i);
+#pragma unroll
+            for (int k = 0; k < 16; k++) if (i + (u64)k < n) atomicAdd(&cnt[LZ_VBYTE(v, k)], 1u);
+        }
     }
     __syncthreads();
     hist[(size_t)blockIdx.x * LZ_NBIN + threadIdx.x] = cnt[threadIdx.x];
@@ -553,11 +557,11 @@ k_hist_scan2(u32* __restrict__ part, u32 nblocks, u32* __restrict__ bin_base)
     for (u32 b = 0; b < nblocks; b++) part[(size_t)b * LZ_NBIN + threadIdx.x] += bb;
 }
 
-int lzk_hist(LzCtx& c, const u64* keys, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st)
+int lzk_hist(LzCtx& c, const u8* bins, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st)
 {
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE), nblocks = (ntiles + 255u) / 256u;
     c.timer.begin("k_hist", st);
-    hipLaunchKernelGGL(k_hist, dim3(ntiles), dim3(LZ_TPB), 0, st, keys, n, hist);
+    hipLaunchKernelGGL(k_hist, dim3(ntiles), dim3(LZ_TPB), 0, st, bins, n, hist);
     c.timer.end(st);
     c.timer.begin("k_hist_scan", st);
     hipLaunchKernelGGL(k_hist_scan1, dim3(nblocks), dim3(LZ_NBIN), 0, st, hist, ntiles, part);
