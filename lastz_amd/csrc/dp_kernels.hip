@@ -51,6 +51,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
     // The serial steps of the DPs that share a CU must not all land on the same SIMD (the waves of a
     // workgroup are dealt out over the four SIMDs in order): the leading wave rotates with the block.
     int lead_wave;
+    s32 cand_wave_max = 0;               // scan_cand -> reduce_row
     __device__ __forceinline__ int lead_lane() const { return lead_wave << 6; }
     template <class F> __device__ __forceinline__ void leader(F&& f)
     {
@@ -85,6 +86,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         s32 inc = x;
         LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
         const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
+        cand_wave_max = __builtin_amdgcn_readlane(inc, 63);     // (reduce_row wants the same maximum: the candidates do not change in walk 3)
         if (wl == 63) sh.wc[w] = inc;
         __syncthreads();
         s32 pre = b0;
@@ -97,10 +99,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
         const s32 lo = has ? (s32)__ffsll((long long)has) - 1 : 0, hi = has ? 63 - (s32)__clzll((long long)has) : 0;
         const u32 first = (u32)__builtin_amdgcn_readlane((s32)regs.first, lo), last = (u32)__builtin_amdgcn_readlane((s32)regs.last, hi);
-        const s32 x = regs.cand;
-        s32 inc = x;
-        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
-        const s32 cmax = __builtin_amdgcn_readlane(inc, 63);
+        const s32 cmax = cand_wave_max;
         const u64 att = __ballot(regs.cand == cmax);            // the LAST lane attaining the max owns the column
         const u32 ccol = (u32)__builtin_amdgcn_readlane((s32)regs.cand_col, 63 - (s32)__clzll((long long)att));
         if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
