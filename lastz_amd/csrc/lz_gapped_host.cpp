@@ -2,6 +2,7 @@
 // DPs are delegated to an LzDpExecutor (the HIP executor in dp_kernels.hip).
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,9 +73,12 @@ static int msp_left_right(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbour
         const size_t o = overflow ? v : cand[nc - 1 - v];
         const LzDpAlign& al = S.aligns[S.obi[o]];
         if (al.end1 < pos1) continue;
-        s32 bp = -1;
-        for (s32 k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].e1 >= pos1) { bp = k; break; }
-        if (bp < 0) continue;
+        // the first piece that ends at or after pos1: e1 never decreases along an alignment (format_segments), so
+        // the reference's linear walk over the pieces is a binary search (long alignments have hundreds of pieces)
+        s32 slo = al.first_seg, shi = al.last_seg + 1;
+        while (slo < shi) { const s32 m = slo + (shi - slo) / 2; if (S.segs[m].e1 >= pos1) shi = m; else slo = m + 1; }
+        if (slo > al.last_seg) continue;
+        const s32 bp = slo;
         const LzDpSeg& g = S.segs[bp];
         if (g.type == LZ_HORZ_SEG) return -1;
         s32 x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
@@ -313,7 +317,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 
     // LZGPU_HOSTPROF=1: where the host time of the stage goes
     static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
-    double t_sort = 0, t_window = 0, t_exec = 0, t_commit = 0;
+    double t_sort = 0, t_window = 0, t_exec = 0, t_commit = 0, t_c_lr = 0, t_c_chk = 0, t_c_build = 0;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now();
     auto lap = [&](double& acc) { const double t = now(); acc += t - t_mark; t_mark = t; };
@@ -464,7 +468,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         for (size_t e = 0; e < entries.size(); e++) {
             const u32 aix = entries[e].anchor_ix;
             Neighbours nb;
+            const double tq0 = prof ? now() : 0;
             int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
+            if (prof) t_c_lr += now() - tq0;
             if (ok < 0) return LZGPU_ERR_STATE;
             if (ok == 0) { cache.erase(aix); continue; }       // lies on an alignment committed meanwhile
             if (!entries[e].speculated) { next = aix; cut = true; break; }    // needs a DP: head of the next window
@@ -488,8 +494,12 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             //     reference would track lies outside the band on every row, whichever neighbours it
             //     starts from, so the DP is the unconstrained one.
             bool same = nb.la == sp.nb.la && nb.ls == sp.nb.ls && nb.ra == sp.nb.ra && nb.rs == sp.nb.rs;
+            const double tq1 = prof ? now() : 0;
             if (same) same = !touched_from(sp.n_snap);
             else      same = !touched_from(0);
+            if (prof) t_c_chk += now() - tq1;
+            const double tq2 = prof ? now() : 0;
+            struct Lap { double& acc; double t0; bool on; std::function<double()> clk; ~Lap() { if (on) acc += clk() - t0; } } lap_build{ t_c_build, tq2, prof, now };
             if (!same) { cache.erase(it); next = aix; cut = true; st.reruns++; break; }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
@@ -515,8 +525,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         if (!cut) next = j;
         lap(t_commit);
     }
-    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, commit %.2f ms (%u rounds)\n",
-                      t_sort, t_window, t_exec, t_commit, (unsigned)st.rounds);
+    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, commit %.2f ms (neighbours %.2f, validity %.2f, build %.2f) (%u rounds)\n",
+                      t_sort, t_window, t_exec, t_commit, t_c_lr, t_c_chk, t_c_build, (unsigned)st.rounds);
 
     // ---- output in increasing start order (orderBegInc), :1475-1566
     for (s32 ai : S.obi) {
