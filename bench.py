@@ -52,7 +52,7 @@ def pmc_traffic(kernel):
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01_v10 after r01_v9, r02 after r01
+                   key=lambda f: ([int(x) for x in re.findall(r"\d+", os.path.basename(f))], os.path.basename(f)))   # r01_v10 after r01_v9, r02 after r01, r02_e after r02_d
     for fn in reversed(files):
         for line in open(fn).read().split("\n")[1:]:
             f = line.split(",")
