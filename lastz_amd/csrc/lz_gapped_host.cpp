@@ -89,6 +89,19 @@ static int msp_left_right(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbour
     return 1;
 }
 
+// does (pos1, pos2) lie on alignment `al` -- msp_left_right's x == 0 for this one alignment
+static bool on_alignment(const LzHostSnapshot& S, const LzDpAlign& al, u32 pos1, u32 pos2)
+{
+    if (al.pos1 > pos1 || al.end1 < pos1) return false;
+    s32 slo = al.first_seg, shi = al.last_seg + 1;
+    while (slo < shi) { const s32 m = slo + (shi - slo) / 2; if (S.segs[m].e1 >= pos1) shi = m; else slo = m + 1; }
+    if (slo > al.last_seg) return false;
+    const LzDpSeg& g = S.segs[slo];
+    if (g.type == LZ_HORZ_SEG) return false;                    // (msp_left_right reports the internal error)
+    const s32 x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+    return x == 0;
+}
+
 // the reference's walk (src/gapped_extend.c:3953-4028), kept as the yardstick of lzh_selftest_neighbours
 static int msp_left_right_plain(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbours& nb)
 {
@@ -366,7 +379,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     const u32 INSURE = 256;
     u32 next = 0;
     std::vector<LzDpJob> jobs; std::vector<LzDpResult> res; std::vector<std::vector<u32>> ops;
-    struct Entry { u32 anchor_ix; bool speculated; };
+    struct Entry { u32 anchor_ix; bool speculated; u32 near_slot; };   // near_slot: the selected anchor a deferred one was found near (its ext_l / ext_r slot)
     // A finished speculative DP pair stays usable across windows for as long as its validity
     // conditions hold against the alignments committed after the snapshot it ran against.
     struct Cached { u32 a1, a2; Neighbours nb; size_t n_snap; LzDpResult rl, rr; std::vector<u32> ol, orr; };
@@ -400,7 +413,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             const s64 cell = (dg >= 0 ? dg : dg - (NEAR_DIAG - 1)) / NEAR_DIAG;
             if (hit == cache.end()) {
                 // 0 = not near, 1 = near (loose), 2 = near and almost on the same diagonal (tight)
-                int near = 0;
+                int near = 0; u32 near_slot = 0;
                 for (s64 cc = cell - 1; cc <= cell + 1 && near < 2; cc++) {
                     auto g = chosen_grid.find(cc);
                     if (g == chosen_grid.end()) continue;
@@ -408,6 +421,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                         if (c.dg - dg <= NEAR_DIAG && dg - c.dg <= NEAR_DIAG &&
                             c.a1 - (s64)a1 <= NEAR_POS && (s64)a1 - c.a1 <= NEAR_POS) {
                             near = (c.dg - dg <= TIGHT_DIAG && dg - c.dg <= TIGHT_DIAG) ? 2 : (near < 1 ? 1 : near);
+                            near_slot = c.ext;
                             if ((s64)a1 < c.a1) { const u32 d = (u32)(c.a1 - (s64)a1); if (d > ext_l[c.ext]) ext_l[c.ext] = d; }
                             else                { const u32 d = (u32)((s64)a1 - c.a1); if (d > ext_r[c.ext]) ext_r[c.ext] = d; }
                             if (near == 2) break;
@@ -416,12 +430,12 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 // a loosely near anchor is usually on the selected anchor's alignment too, but when it is not it
                 // costs a whole extra round for one DP: a bounded number of them is speculated anyway
                 if (near == 1 && insured < INSURE) { insured++; near = 0; }
-                if (near) { entries.push_back({ j, false }); continue; }
+                if (near) { entries.push_back({ j, false, near_slot }); continue; }
             }
             ext_of[j] = (u32)ext_l.size();
             chosen_grid[cell].push_back({ dg, (s64)a1, (u32)ext_l.size() });
             ext_l.push_back(0); ext_r.push_back(0);
-            entries.push_back({ j, true });
+            entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
             s32 below = -1, above = -1;
@@ -465,10 +479,18 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 
         // ---- commit in the reference's order
         bool cut = false;
+        std::vector<s32> slot_align(ext_l.size(), -1);        // alignment committed for a selected anchor of this window
         for (size_t e = 0; e < entries.size(); e++) {
             const u32 aix = entries[e].anchor_ix;
             Neighbours nb;
             const double tq0 = prof ? now() : 0;
+            // A deferred anchor nearly always lies on the alignment of the selected anchor it was found near: that
+            // alignment first (one binary search); "on an alignment" needs no more than one witness (:3953-4028)
+            if (!entries[e].speculated && entries[e].near_slot < slot_align.size() && slot_align[entries[e].near_slot] >= 0
+                && on_alignment(S, S.aligns[slot_align[entries[e].near_slot]], anchors[aix].pos1, anchors[aix].pos2)) {
+                if (prof) t_c_lr += now() - tq0;
+                cache.erase(aix); continue;
+            }
             int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
             if (prof) t_c_lr += now() - tq0;
             if (ok < 0) return LZGPU_ERR_STATE;
@@ -521,6 +543,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             in.script.swap(b.script);
             info.push_back(std::move(in));
             insert_align(S, (s32)S.aligns.size() - 1);
+            if (entries[e].near_slot < slot_align.size()) slot_align[entries[e].near_slot] = (s32)S.aligns.size() - 1;
         }
         if (!cut) next = j;
         lap(t_commit);
