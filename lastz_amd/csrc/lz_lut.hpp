@@ -53,11 +53,7 @@ struct LzLutScan { u32 s; s32 run, best; u32 room, used, alive, nwin; };   // al
 
 #if defined(__HIP_DEVICE_COMPILE__)
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-#if defined(LZ_EXPERIMENT_NODOT)                                // timing experiment only (wrong results): what the v_dot4 pair costs
-LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return acc + (s32)a; }
-#else
 LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return __builtin_amdgcn_sdot4((int)a, 0x01010101, acc, false); }
-#endif
 LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k)    // (byte k of hi_src) << 8 | byte k of lo_src
 { return __builtin_amdgcn_perm(hi_src, lo_src, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k); }
 #define LZ_UNROLL_ALL _Pragma("unroll")
@@ -322,9 +318,6 @@ LZ_HD void lz_settle_record(const LzExtendParams& P, const s32* score_tab, u64 r
         if (extent > dend) dend = extent;
         return;
     }
-#if defined(LZ_EXPERIMENT_NOSLOW)                               // timing experiment only (results are wrong): what phase B costs without re-extensions
-    dend = p2 + 100; return;
-#endif
     const s32 diag = (s32)((pay << 16) | h);
     dend = lz_reextend(P, score_tab, p2, diag, dend, n_bp, emit);
 }
