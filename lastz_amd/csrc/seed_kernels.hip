@@ -783,6 +783,8 @@ static void lz_scan_geometry(LzCtx& c, u64 n, u32& grid, u32& n_regions, u32& re
     grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
     n_regions = grid * (LZ_SC_TPB / 64);
     region_cap = (u32)std::min<u64>(n / 8 / n_regions + 64, 1u << 20);
+    static const char* force = getenv("LZGPU_TASK_REGION_CAP");  // test hook: tiny regions, so that hits find theirs full
+    if (force && atoi(force) > 0) region_cap = (u32)atoi(force);
 }
 // buffers of a set for chunks of up to max_n hits (sized once per search: chunk sizes differ a little, and a
 // device buffer that grows is freed and allocated again)

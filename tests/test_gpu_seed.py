@@ -295,6 +295,29 @@ def test_three_stream_chunk_pipeline(gpu, tmp_path):
     assert r.returncode == 0 and "pipeline ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_full_task_regions_leave_hits_to_phase_b(gpu, tmp_path):
+    """a scan that goes on past its first window becomes a task in its wave's region of the task list; with the
+    regions forced down to two entries most such hits find theirs full, stay "alive" and are extended exactly by
+    phase B instead -- same HSPs, same counters (fresh process: the cap is read once)"""
+    t, q = seqio.synth_pair(1_000_000, 1_000_000, seed=31)
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    want = [_same_hsps(gpu, tab, qq, masked) for _, _, qq in H.strands(q)]
+    np.save(tmp_path / "w0.npy", want[0]); np.save(tmp_path / "w1.npy", want[1])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from lastz_amd import seqio, lzgpu; import helpers as H; from oracle import lzo\n"
+            "g = lzgpu.Lib(); g.init()\n"
+            "t, q = seqio.synth_pair(1_000_000, 1_000_000, seed=31); _, masked = H.scoring()\n"
+            "g.table_prepare(t, g.seed(H.DEFAULT_SEED, 1), lzo.upper_nuc_to_bits())\n"
+            "for k, (_, _, qq) in enumerate(H.strands(q)):\n"
+            "    got = g.seed_hit_search(masked, q=qq); want = np.load(%r %% k)\n"
+            "    assert len(got) == len(want) and (got == want).all(), k\n"
+            "print('regions ok')\n" % (H.ROOT, os.path.join(H.ROOT, "tests"), str(tmp_path / "w%d.npy")))
+    env = dict(os.environ); env["LZGPU_TASK_REGION_CAP"] = "2"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "regions ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_full_size_properties(gpu):
     """BASELINE.json configs[1] size (50 Mbp x 50 Mbp, one strand): properties that do not
     need the oracle -- determinism, chunk-capacity invariance, every HSP re-scores to its score on
