@@ -162,12 +162,12 @@ k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ re
 }
 
 struct DpBufs {
-    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings;
+    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings, sel_jobs, sel_res;
 };
 static DpBufs g_dp;
 void lz_dp_release_statics()
 {
-    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings };
+    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings, &g_dp.sel_jobs, &g_dp.sel_res };
     for (DevBuf* x : b) x->release();
 }
 
@@ -259,9 +259,9 @@ struct HipDpExec : LzDpExecutor {
         for (u32 id : ids) { sel.push_back(jobs[id]); selr.push_back(res[id]); seloff.push_back(total); total += res[id].n_ops; }
         if (total == 0) return 0;
         int rc;
-        DevBuf dj, dr;
+        DevBuf& dj = g_dp.sel_jobs; DevBuf& dr = g_dp.sel_res;      // (kept: a hipMalloc / hipFree pair per launch is not free)
         if ((rc = dj.ensure(sel.size() * sizeof(LzDpJob)))) return rc;
-        if ((rc = dr.ensure(selr.size() * sizeof(LzDpResult)))) { dj.release(); return rc; }
+        if ((rc = dr.ensure(selr.size() * sizeof(LzDpResult)))) return rc;
         if ((rc = g_dp.ops_off.ensure(seloff.size() * 8))) return rc;
         if ((rc = g_dp.ops_out.ensure(total * 4))) return rc;
         LZ_HIP(hipMemcpyAsync(dj.p, sel.data(), sel.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
@@ -273,7 +273,6 @@ struct HipDpExec : LzDpExecutor {
         std::vector<u32> flat(total);
         LZ_HIP(hipMemcpyAsync(flat.data(), g_dp.ops_out.p, total * 4, hipMemcpyDeviceToHost, c.stream));
         LZ_HIP(hipStreamSynchronize(c.stream));
-        dj.release(); dr.release();
         for (size_t k = 0; k < ids.size(); k++)
             ops[ids[k]].assign(flat.begin() + seloff[k], flat.begin() + seloff[k] + res[ids[k]].n_ops);
         return 0;

@@ -387,7 +387,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::vector<Entry> entries;
     std::vector<u32> fresh;                                    // anchors launched in this round
     struct Chosen { s64 dg, a1; u32 ext; };                    // a selected anchor of this window, and its slot in ext_l / ext_r
-    std::unordered_map<s64, std::vector<Chosen>> chosen_grid;
+    // cells of NEAR_DIAG diagonals, directly indexed (diagonals run from -qlen to tlen); `touched` lists the cells in use
+    const s64 cell_lo = -(s64)(G.qlen / NEAR_DIAG) - 2;
+    std::vector<std::vector<Chosen>> chosen_grid((size_t)((s64)(G.tlen / NEAR_DIAG) + 2 - cell_lo + 1));
+    std::vector<u32> touched;
     // How far the deferred anchors near a selected one reach on either side of it: a guess at the rows its two DPs
     // will sweep (the anchors an alignment swallows line up along it).  Only the launch order uses it -- a launch
     // lasts as long as its longest DP, so the long ones should be among the first resident.
@@ -395,7 +398,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::unordered_map<u32, u32> ext_of;                       // anchor index -> slot
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        jobs.clear(); entries.clear(); chosen_grid.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear();
+        jobs.clear(); entries.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear();
+        for (u32 t : touched) chosen_grid[t].clear();
+        touched.clear();
         u32 insured = 0;
         u32 j = next;
         const u32 scan_limit = 64 * W;
@@ -415,9 +420,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 // 0 = not near, 1 = near (loose), 2 = near and almost on the same diagonal (tight)
                 int near = 0; u32 near_slot = 0;
                 for (s64 cc = cell - 1; cc <= cell + 1 && near < 2; cc++) {
-                    auto g = chosen_grid.find(cc);
-                    if (g == chosen_grid.end()) continue;
-                    for (auto& c : g->second)
+                    const s64 gi = cc - cell_lo;
+                    if (gi < 0 || gi >= (s64)chosen_grid.size()) continue;
+                    for (auto& c : chosen_grid[(size_t)gi])
                         if (c.dg - dg <= NEAR_DIAG && dg - c.dg <= NEAR_DIAG &&
                             c.a1 - (s64)a1 <= NEAR_POS && (s64)a1 - c.a1 <= NEAR_POS) {
                             near = (c.dg - dg <= TIGHT_DIAG && dg - c.dg <= TIGHT_DIAG) ? 2 : (near < 1 ? 1 : near);
@@ -433,7 +438,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 if (near) { entries.push_back({ j, false, near_slot }); continue; }
             }
             ext_of[j] = (u32)ext_l.size();
-            chosen_grid[cell].push_back({ dg, (s64)a1, (u32)ext_l.size() });
+            { const size_t gi = (size_t)(cell - cell_lo); if (chosen_grid[gi].empty()) touched.push_back((u32)gi); chosen_grid[gi].push_back({ dg, (s64)a1, (u32)ext_l.size() }); }
             ext_l.push_back(0); ext_r.push_back(0);
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
