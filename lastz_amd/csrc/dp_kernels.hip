@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
@@ -400,7 +401,11 @@ extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint
     G.strands_differ = a->strands_differ != 0; G.inhibit_trivial = a->inhibit_trivial != 0;
     if ((a->sep1 && a->n_sep1 < 2) || (a->sep2 && a->n_sep2 < 2)) return lz_fail(LZGPU_ERR_ARG, "a partitioned sequence needs at least two separators");
     if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
+    static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
+    const auto tq0 = std::chrono::steady_clock::now();
     if (a->reduce) lzh_reduce_to_points(G.t, G.q, G.sub, a->anchors, a->n_anchors);
+    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: reduce_to_points of %u anchors %.2f ms\n", a->n_anchors,
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
     std::vector<lz_align> al; std::vector<u32> op; LzGappedStats st;
     rc = lzh_gapped_extend(G, ex, a->anchors, a->n_anchors, al, op, st);
     c.counters.anchors_extended += st.anchors_extended;

@@ -2,6 +2,7 @@
 // DPs are delegated to an LzDpExecutor (the HIP executor in dp_kernels.hip).
 #include <string.h>
 #include <algorithm>
+#include <thread>
 #include <functional>
 #include <chrono>
 #include <stdio.h>
@@ -32,10 +33,18 @@ static u32 segment_peak(const u8* s1, const u8* s2, u32 len, const s32* sub)
 
 void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* segs, u32 n)
 {
-    for (u32 i = 0; i < n; i++) {
-        u32 peak = segment_peak(t + segs[i].pos1, q + segs[i].pos2, segs[i].length, sub);
-        segs[i].pos1 += peak; segs[i].pos2 += peak; segs[i].length = 0;
-    }
+    // independent per anchor: a few threads (8.8 -> ~2 ms for the 78 k anchors of a 50 Mbp strand)
+    auto part = [&](u32 lo, u32 hi) {
+        for (u32 i = lo; i < hi; i++) {
+            u32 peak = segment_peak(t + segs[i].pos1, q + segs[i].pos2, segs[i].length, sub);
+            segs[i].pos1 += peak; segs[i].pos2 += peak; segs[i].length = 0;
+        }
+    };
+    const u32 nt = n < 8192 ? 1u : 8u;
+    if (nt == 1) { part(0, n); return; }
+    std::vector<std::thread> th;
+    for (u32 k = 0; k < nt; k++) th.emplace_back(part, (u32)((u64)n * k / nt), (u32)((u64)n * (k + 1) / nt));
+    for (auto& x : th) x.join();
 }
 
 // qSegmentsByDecreasingScore, src/segment.c:1748-1771 (a total order up to identical records)
