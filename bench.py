@@ -302,7 +302,7 @@ def run_single(a, torch, lib):
             segs.append(sg)
         for slot in (0, 1):
             lib.gapped_extend(sub, segs[slot].copy(), slot=slot, ydrop=9430)       # warm-up (allocations)
-        lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
+        lib.profile_enable(True); lib.profile_reset(); lib.counters_reset(); lib.dp_longest(reset=True)
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         nblocks = 0
@@ -314,11 +314,16 @@ def run_single(a, torch, lib):
         gpr, gc = lib.profile(), lib.counters()
         lib.profile_enable(False)
         kms = gpr.get("k_ydrop", {"ms": 0.0, "launches": 0})
+        dpl = lib.dp_longest()
         gapped = {"workload": "BASELINE.json configs[2]: same pair, gapped stage, --ydrop=9430, both strands",
                   "wall_s": gdt, "anchors": int(len(segs[0]) + len(segs[1])), "alignments": nblocks,
                   "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"],
                   "dp_cells_reference": gc["dp_cells"], "gcups_wall": gc["dp_cells"] / gdt / 1e9,
                   "k_ydrop_ms": kms["ms"], "k_ydrop_launches": kms["launches"],
+                  # a launch lasts as long as its longest DP: shader cycles per row of that DP
+                  "longest_dp": {"rows": dpl["rows"], "cells": dpl["cells"],
+                                 "cycles_per_row": (dpl["sweep_ticks"] / dpl["rows"]) if dpl["rows"] else None,
+                                 "traceback_cycles": dpl["traceback_ticks"]},
                   "kernel_ms": {k: v["ms"] for k, v in gpr.items()},
                   # algorithmic bytes of the DP, SURVEY 8(d): 1 traceback byte per visited cell
                   "roofline": {"bound": "hbm", "kernel": "k_ydrop",
@@ -328,6 +333,11 @@ def run_single(a, torch, lib):
                                "traffic": None}}
         if gold:
             gapped["alignments_ok"] = (nblocks == gold["lav_blocks"])
+            # the reference's own gapped stage on this pair: the difference of its two whole runs (1 core each,
+            # measured where the golden fingerprints were made, tests/golden/make_bench_sha.py)
+            ref_s = gold["reference_wall_s"]["gapped"] - gold["reference_wall_s"]["nogapped"]
+            gapped["cpu_reference"] = {"stage_s_1core": ref_s, "gcups_1core": gc["dp_cells"] / ref_s / 1e9,
+                                       "speedup": ref_s / gdt, "source": "tests/golden/bench50m.sha.json (reference_wall_s gapped - nogapped)"}
 
     # ---- the lastz CLI bound to this library on the same pair: wall clock + the LAV's fingerprint
     cli = None

@@ -242,6 +242,10 @@ int lzgpu_set_hit_capacity(uint64_t max_hits_per_chunk);
 int lzgpu_set_hsp_capacity(uint64_t max_candidate_hsps);
 int lzgpu_set_dp_slot(uint32_t first_try_traceback_bytes_per_dp);
 int lzgpu_set_dp_window(uint32_t max_anchors_speculated_per_round);
+/* the one-sided DP that swept the most rows since the last reset: out = { rows, cells, shader-clock ticks of the row
+ * sweep, ticks of the traceback } (a launch lasts as long as its longest DP: ticks / rows is the figure of merit of
+ * k_ydrop) */
+int lzgpu_dp_longest(uint64_t out[4], int reset);
 
 /* Sharding INSIDE one query (exact alternative (1) for the HSP stage): the only cross-hit state of
  * seed_hit_search is diagEnd[hashedDiag] (src/diag_hash.h:61-64), so the 65,536 buckets can be dealt out to

@@ -172,6 +172,14 @@ void lz_dp_release_statics()
     for (DevBuf* x : b) x->release();
 }
 
+static u64 g_dp_longest[4] = { 0, 0, 0, 0 };
+extern "C" int lzgpu_dp_longest(uint64_t out[4], int reset)
+{
+    if (out) for (int k = 0; k < 4; k++) out[k] = g_dp_longest[k];
+    if (reset) for (int k = 0; k < 4; k++) g_dp_longest[k] = 0;
+    return 0;
+}
+
 struct HipDpExec : LzDpExecutor {
     LzCtx& c;
     LzDpParams P;                        // arenas filled per launch
@@ -228,6 +236,10 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipStreamSynchronize(c.stream));
         c.timer.resolve();
         for (u32 id : ids) res[id] = all[id];
+        for (u32 id : ids)                                       // the DP that swept the most rows since the last reset (lzgpu_dp_longest)
+            if (all[id].status == LZ_DP_OK && all[id].max_row > g_dp_longest[0]) {
+                g_dp_longest[0] = all[id].max_row; g_dp_longest[1] = all[id].cells; g_dp_longest[2] = all[id].t_rows; g_dp_longest[3] = all[id].t_trace;
+            }
         if (getenv("LZGPU_DPPROF")) {
             u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0; u64 ph[4] = { 0, 0, 0, 0 }, ld[5] = { 0, 0, 0, 0, 0 };
             for (u32 id : ids) { sum_r += all[id].t_rows; sum_t += all[id].t_trace;

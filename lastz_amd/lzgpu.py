@@ -60,7 +60,7 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdo
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_table_save", "lzgpu_table_load", "lzgpu_device_copy",
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
-           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window",
+           "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window", "lzgpu_dp_longest",
            "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode"]
 
 
@@ -287,6 +287,12 @@ class Lib:
 
     def set_dp_window(self, n):
         self._check(self.L.lzgpu_set_dp_window(n), "set_dp_window")
+
+    def dp_longest(self, reset=False):
+        """{rows, cells, sweep_ticks, traceback_ticks} of the DP that swept the most rows since the last reset"""
+        out = (C.c_uint64 * 4)()
+        self.L.lzgpu_dp_longest(out, int(reset))
+        return dict(zip(("rows", "cells", "sweep_ticks", "traceback_ticks"), (int(v) for v in out)))
 
     def profile_enable(self, on=True):
         self.L.lzgpu_profile_enable(int(on))
