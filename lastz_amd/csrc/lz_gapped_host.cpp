@@ -395,6 +395,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     std::unordered_map<u32, Cached> cache;
     std::vector<Entry> entries;
     std::vector<u32> fresh;                                    // anchors launched in this round
+    // the alignment committed for the selected anchor a deferred anchor was found near, remembered across windows:
+    // when a window is cut, the anchors behind the cut are scanned again and most of them lie on that alignment
+    std::vector<s32> near_align(n_anchors, -1);
     struct Chosen { s64 dg, a1; u32 ext; };                    // a selected anchor of this window, and its slot in ext_l / ext_r
     // cells of NEAR_DIAG diagonals, directly indexed (diagonals run from -qlen to tlen); `touched` lists the cells in use
     const s64 cell_lo = -(s64)(G.qlen / NEAR_DIAG) - 2;
@@ -417,6 +420,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         for (; j < n_anchors && fresh.size() < W && entries.size() < scan_limit; j++) {
             const u32 a1 = anchors[j].pos1, a2 = anchors[j].pos2;
             Neighbours nb;
+            if (near_align[j] >= 0 && on_alignment(S, S.aligns[near_align[j]], a1, a2)) { cache.erase(j); continue; }
             int ok = msp_left_right(S, a1, a2, nb);
             if (ok < 0) return LZGPU_ERR_STATE;
             if (ok == 0) { cache.erase(j); continue; }         // on an earlier alignment: gone for good
@@ -559,6 +563,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             insert_align(S, (s32)S.aligns.size() - 1);
             if (entries[e].near_slot < slot_align.size()) slot_align[entries[e].near_slot] = (s32)S.aligns.size() - 1;
         }
+        if (cut) for (size_t e = 0; e < entries.size(); e++)    // for the scan of the next window
+            if (!entries[e].speculated && entries[e].near_slot < slot_align.size()) near_align[entries[e].anchor_ix] = slot_align[entries[e].near_slot];
         if (!cut) next = j;
         lap(t_commit);
     }
