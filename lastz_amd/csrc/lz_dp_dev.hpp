@@ -115,13 +115,17 @@ struct LzDpRingHbm {
     LZ_HD void bind(u8* slot) { cc = (s32*)slot; dd = cc + LZ_DP_WIDEW; mk = (u32*)(dd + LZ_DP_WIDEW); lk = (u8*)(mk + LZ_DP_WIDEW); bb = lk + LZ_DP_WIDEW; }
 };
 struct LzDpSharedBase {
+    // what lane 0 publishes for the other lanes before each row (its own sweep state is LzDpCtl): sixteen words,
+    // written together at the end of the lane-0 step and read together behind its barrier (four 128-bit LDS
+    // accesses each way instead of sixteen / ten scattered ones)
+    alignas(16) u32 row; u32 LY, ry_iter, cpl;
+    s32 best; u32 trow_cur, n_act, done;
+    u32 extra, fill_n, fill_base, fill_trow;              // work for all lanes before the next row
+    u32 stage_lo, stage_a; s32 fill_i; u32 b_hi;
     u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
     // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
     LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
     u32 r_first, r_last, r_ccol; s32 r_cmax;
-    // what lane 0 publishes for the other lanes before each row (its own sweep state is LzDpCtl)
-    u32 LY, row, cpl, ry_iter, n_act, done, trow_cur, b_hi; s32 best;
-    u32 extra, fill_n, fill_base, fill_trow, stage_lo, stage_a; s32 fill_i;   // work for all lanes before the next row
     // traceback state
     u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
     u8  tb_win[64];
@@ -420,6 +424,9 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         const u64 ts = LZ_PHASE_CLOCK();
         x.leader([&]() {
             u64 q0 = LZ_PHASE_CLOCK(), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+            // (published at the end, in one block)
+            u32 p_fill_n = 0, p_fill_base = 0, p_fill_trow = 0, p_stage_lo = ct.b_hi, p_stage_a = 0, p_trow_cur = 0, p_ry_iter = 0, p_cpl = 0, p_extra = 0;
+            s32 p_fill_i = 0;
             [&]() {
             u32 extra = 0;
             if (swept) {
@@ -452,21 +459,20 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                         sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
                         tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
                     }
-                    sh.fill_n = 0;
-                } else { sh.fill_n = np; sh.fill_base = RY - np; sh.fill_i = i_last; sh.fill_trow = trow_cur; extra = 1; }
+                } else { p_fill_n = np; p_fill_base = RY - np; p_fill_i = i_last; p_fill_trow = trow_cur; extra = 1; }
                 tb_used += np;
                 if (RY - 1 > ct.max_col) ct.max_col = RY - 1;
                 if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; RY++; }   // terminating cell, :3818-3826
                 ct.RY = RY; ct.tb_used = tb_used;
                 // B classes of the columns the next row may reach; every LZ_DP_LANES rows the next block of A classes
                 u32 bh = ct.b_hi;
-                sh.stage_lo = bh;
+                p_stage_lo = bh;
                 while (RY + 2 > bh) { bh += LZ_DP_LANES; extra = 1; }
                 ct.b_hi = bh;
-                sh.stage_a = ((row & (LZ_DP_LANES - 1)) == 0) ? row + 1 : 0;
-                if (sh.stage_a) extra = 1;
+                p_stage_a = ((row & (LZ_DP_LANES - 1)) == 0) ? row + 1 : 0;
+                if (p_stage_a) extra = 1;
             }
-            sh.extra = extra;
+            p_extra = extra;
             q2 = LZ_PHASE_CLOCK();
             // set-up of the next row: bounds, active segments, traceback budget
             if (ct.row >= M) { ct.done = 1; return; }
@@ -484,11 +490,14 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             if ((u64)ct.tb_used + (u64)tb_needed > (u64)J.tb_cap) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; return; }
             if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > SH::RING) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; return; }
             if (ct.row + 1 >= J.row_cap) { ct.status = LZ_DP_ROW_SLOT; ct.done = 1; return; }
-            trow[ct.row] = sh.trow_cur = ct.tb_used - ct.LY;    // tbRow[row], :3662 (u32 wrap intended)
-            sh.ry_iter = ct.RY;
-            sh.cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
+            trow[ct.row] = p_trow_cur = ct.tb_used - ct.LY;     // tbRow[row], :3662 (u32 wrap intended)
+            p_ry_iter = ct.RY;
+            p_cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
             }();
-            sh.done = ct.done; sh.row = ct.row; sh.LY = ct.LY; sh.best = ct.best; sh.n_act = ct.n_act; sh.b_hi = ct.b_hi;
+            sh.row = ct.row; sh.LY = ct.LY; sh.ry_iter = p_ry_iter; sh.cpl = p_cpl;
+            sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.n_act = ct.n_act; sh.done = ct.done;
+            sh.extra = p_extra; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
+            sh.stage_lo = p_stage_lo; sh.stage_a = p_stage_a; sh.fill_i = p_fill_i; sh.b_hi = ct.b_hi;
             const u64 q5 = LZ_PHASE_CLOCK();
             if (q1 < q0) q1 = q0; if (q2 < q1) q2 = q1; if (q3 < q2) q3 = q2; if (q4 < q3) q4 = q3;
             tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += q5 - q4;
