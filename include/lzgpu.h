@@ -11,7 +11,10 @@
  *
  * Conventions (reference default build): positions are u32 (unspos), scores s32, sequences are
  * one ASCII byte per base.  All functions are called from one host thread (the reference is
- * single-threaded and non-reentrant, src/seed_search.c:364-365).
+ * single-threaded and non-reentrant, src/seed_search.c:364-365).  The library is a process-wide singleton: one device
+ * context, one resident target / table, function-static caches (the last scoring matrix, compared by value, with its
+ * class codes and look-up table; the DP arenas) -- calls from two threads, even on different sequences, are not
+ * supported; the library itself uses a few worker threads for host-side loops and joins them before returning.
  *
  * Return codes, every int-returning entry point:
  *     0   done, results are complete and bit-identical to the reference's
