@@ -938,7 +938,9 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 #define LZ_ST_TILE   4096
 #endif
 #define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
+#ifndef LZ_ST_BATCH
 #define LZ_ST_BATCH  4
+#endif
 __global__ void __launch_bounds__(LZ_ST_TPB)
 k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__ bin_base, u32* __restrict__ diag_end,
          const s32* __restrict__ score_tab_g, LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap,
