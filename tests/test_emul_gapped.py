@@ -107,3 +107,24 @@ def test_bands_wider_than_the_lds_ring(L, kw):
     _, q = seqio.read_fasta(os.path.join(H.GOLDEN, "pseudopig.fa"))[0]
     st = _check(L, tgt, q, **kw)
     assert st["wide_runs"] > 0
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_speculation_windows_on_random_obstacle_courses(L, seed):
+    """the acceptance rule of the speculative windows (a result is kept iff the reference would have run the same DP:
+    same neighbours and nothing committed since touches what it explored, or nothing at all touches it) against
+    the oracle on random pairs crowded with tandem repeats and overlapping homology, for window sizes from the
+    reference's serial loop (1) to everything at once; every window size must also launch what it commits"""
+    rng = np.random.default_rng(seed)
+    t, q = seqio.synth_pair(6000, 6000, seed=seed, block_min=300, block_max=2000, homolog_frac=0.85)
+    t = t.copy(); q = q.copy()
+    unit = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(17, 41)))
+    rep = np.tile(unit, 40)
+    for arr, n_rep in ((t, 2), (q, 3)):
+        for _ in range(n_rep):
+            s0 = int(rng.integers(0, len(arr) - len(rep))); n = int(rng.integers(len(rep) // 3, len(rep)))
+            arr[s0:s0 + n] = rep[:n]
+    q[1000:2200] = t[3500:4700]                                  # a second copy of a target block: competing alignments
+    stats = [_check(L, t, q, window=w) for w in (1, 1024)]
+    assert stats[0]["rounds"] >= stats[1]["rounds"]
+    assert stats[0]["anchors_extended"] == stats[1]["anchors_extended"]
