@@ -172,7 +172,7 @@ void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab)
 {
     s32 F[4][2] = { { 0 } };
     lut_classes(M4, F);
-    for (int dir = 0; dir < 1; dir++)                           // bases consumed low to high (left scans are mirrored when fetched)
+    for (int dir = 0; dir < 2; dir++)                           // 0: bases consumed low to high inside a byte (right scans); 1: high to low (left scans)
         for (u32 idx = 0; idx < LZ_LUT_ENTRIES; idx++) {
             const u32 xb = idx & 0xFFu, wn = idx >> 8;
             s32 p = 0, minp = 0x7FFFFFFF, maxp = -0x7FFFFFFF; u32 sc = 0;

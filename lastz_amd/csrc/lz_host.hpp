@@ -17,7 +17,7 @@ double lzh_hsp_entropy(const u8* s, const u8* t, int len);
 // codes -- M4 receives the 4 x 4 matrix over charToBits codes -- else 0 (the byte-code scans run instead).
 struct LzLutEntry;
 int  lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], const u8 qocc[256], s32 xdrop, s32 M4[16]);
-void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab /*[4096]*/);
+void lzh_lut_build(const s32 M4[16], s32 xdrop, LzLutEntry* tab /*[LZ_LUT_TOTAL]*/);
 
 struct LzChunk { u32 i0, i1; u64 base, nh; };
 // Split query positions [0,n) into chunks of at most cap raw hits.  off_at(i) must return the

@@ -19,10 +19,13 @@
 // invariant under complementing both bases (M[a][b] == M[3-a][3-b]: every strand-symmetric DNA matrix, HOXD70
 // included) the score depends on x = t ^ q and the low bit of t only: 3 bits per base, 12 bits per group of
 // four, 4096 entries of 8 bytes.  Four bases are one byte of the code stream, so that a group's index is one byte
-// of (t ^ q) and one nibble of the compressed low-bit plane of t.  There is ONE table, for bases consumed in
-// ascending order: the window of a left scan is turned around when it is fetched (the 16 bytes that end at the
-// scan position, base order reversed: v_bfrev + a swap of neighbouring bits per word), after which loop 1 is loop 2
-// on the mirrored strings -- 32 KiB of LDS instead of 64, which is what lets two workgroups share a CU.
+// of (t ^ q) and one nibble of the compressed low-bit plane of t.  There are TWO tables of 4096 entries: one for
+// bases consumed in ascending order inside a byte (loop 2) and one for descending order (loop 1: the 16 bytes
+// that END at the scan position are shifted so that the first base consumed is the top pair of byte 14 and group g
+// is byte 14 - g) -- 64 KiB of LDS, two workgroups per CU on the 160 KiB of gfx950.  (Round 2 kept one table and
+// turned the left window around with v_bfrev + a swap of neighbouring bits per word: 32 VALU instructions per hit
+// in a kernel that is bound by VALU issue.)  Entries are 8-byte aligned: one ds_read_b64 per group (a 4-byte
+// aligned struct compiled to ds_read2_b32: two banked passes per look-up).
 //
 // Bytes outside the 2-bit alphabet ("specials": lower case, N, the NUL between partitions, ...) are kept in a
 // separate 1-bit-per-base mask.  The LUT path is only taken when every special byte that OCCURS in the two
@@ -35,13 +38,14 @@
 #include "lz_common.hpp"
 
 #define LZ_PAD2         128          // padding bases in front of base 0 in the 2-bit and mask arrays (and >= that after the end)
-#define LZ_LUT_ENTRIES  4096         // 4 bases x 3 bits
+#define LZ_LUT_ENTRIES  4096         // 4 bases x 3 bits, per direction
+#define LZ_LUT_TOTAL    (2 * LZ_LUT_ENTRIES)   // [0, 4096): ascending (right scans), [4096, 8192): descending (left scans)
 #define LZ_LUT_WIN_G    15           // groups per 16-byte window
 #define LZ_LUT_WIN_B    60           // bases per window
 #define LZ_LUT_MAXWIN   3            // windows per scan (180 bases); a scan still alive after that makes the hit SLOW
 #define LZ_GRAY(c)      ((c) ^ ((c) >> 1))      // 2-bit code as stored in the phase-A arrays
 
-struct LzLutEntry { u32 ab; u32 sc; };          // ab = A (u16) | B' (s16) << 16; sc = the four scores, signed bytes, first consumed in byte 0
+struct alignas(8) LzLutEntry { u32 ab; u32 sc; };          // ab = A (u16) | B' (s16) << 16; sc = the four scores, signed bytes, first consumed in byte 0
 
 struct LzLutParams {
     const u8* t2; const u8* q2;                   // Gray 2-bit codes: base i at bits 2*((i+PAD2)&3) of byte (i+PAD2)>>2
@@ -54,12 +58,14 @@ struct LzLutScan { u32 s; s32 run, best; u32 room, used, alive, nwin; };   // al
 #if defined(__HIP_DEVICE_COMPILE__)
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 LZ_HD s32 lz_sdot4(u32 a, s32 acc) { return __builtin_amdgcn_sdot4((int)a, 0x01010101, acc, false); }
+LZ_HD s32 lz_sdot4m(u32 a, u32 ones, s32 acc) { return __builtin_amdgcn_sdot4((int)a, (int)ones, acc, false); }   // acc + the bytes of a that `ones` selects
 LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k)    // (byte k of hi_src) << 8 | byte k of lo_src
 { return __builtin_amdgcn_perm(hi_src, lo_src, 0x0C0C0000u | ((u32)(4 + k) << 8) | (u32)k); }
 #define LZ_UNROLL_ALL _Pragma("unroll")
 #else
 LZ_HD u32 lz_alignbit(u32 hi, u32 lo, u32 sh) { sh &= 31u; return sh ? (lo >> sh) | (hi << (32u - sh)) : lo; }
 LZ_HD s32 lz_sdot4(u32 a, s32 acc) { for (int k = 0; k < 4; k++) acc += (s32)(int8_t)(a >> (8 * k)); return acc; }
+LZ_HD s32 lz_sdot4m(u32 a, u32 ones, s32 acc) { for (int k = 0; k < 4; k++) acc += (s32)(int8_t)(a >> (8 * k)) * (s32)((ones >> (8 * k)) & 0xFFu); return acc; }
 LZ_HD u32 lz_byte_pair(u32 hi_src, u32 lo_src, int k) { return (((hi_src >> (8 * k)) & 0xFFu) << 8) | ((lo_src >> (8 * k)) & 0xFFu); }
 #define LZ_UNROLL_ALL
 #endif
@@ -69,31 +75,22 @@ LZ_HD u32 lz_clz64(u64 x) { return (u32)__builtin_clzll(x); }
 // the raw bytes of one window: 16 bytes of each code stream (+ 16 bytes of each special mask)
 template <bool SPECIAL> struct LzLutRaw { LzVec16 tv, qv, tm, qm; };
 template <> struct LzLutRaw<false> { LzVec16 tv, qv; };
-// group g of a window is byte g of the aligned stream: base s (RIGHT) resp. base s-1 (LEFT, mirrored) at bit 0.
-LZ_HD u32 lz_pairrev32(u32 x)                                   // the 16 two-bit codes of a word in reverse order
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const u32 y = __builtin_bitreverse32(x);
-#else
-    u32 y = 0; for (int k = 0; k < 32; k++) y |= ((x >> k) & 1u) << (31 - k);
-#endif
-    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-}
+// group g of a window is byte g of the aligned stream with base s at bit 0 (RIGHT), resp. byte 14 - g with base s-1
+// in the top pair of byte 14 (LEFT)
+#define LZ_LUT_GBYTE(RIGHT_, g_) ((RIGHT_) ? (g_) : 14 - (g_))
 template <bool RIGHT, bool SPECIAL>
 LZ_HD void lz_lut_fetch(const LzLutParams& P, u32 s_, s32 diag, LzLutRaw<SPECIAL>& raw)
 {
-    const s64 s = (s64)s_, sq = s - (s64)diag;
-    if (RIGHT) { raw.tv = lz_load16(P.t2 + ((u64)(s + LZ_PAD2) >> 2)); raw.qv = lz_load16(P.q2 + ((u64)(sq + LZ_PAD2) >> 2)); }
-    else {
-        // the 16 bytes that end with the byte of base s-1, mirrored: that base (pair 60 + r' of the 64 loaded) becomes
-        // pair 3 - r', which lz_lut_window's right shift of 2 (3 - r') bits brings to bit 0
-        const LzVec16 a = lz_load16(P.t2 + ((u64)(s - 1 + LZ_PAD2) >> 2) - 15), b = lz_load16(P.q2 + ((u64)(sq - 1 + LZ_PAD2) >> 2) - 15);
-        LZ_UNROLL_ALL
-        for (int k = 0; k < 4; k++) { raw.tv.w[k] = lz_pairrev32(a.w[3 - k]); raw.qv.w[k] = lz_pairrev32(b.w[3 - k]); }
-    }
+    // byte offsets fit 32 bits (sequences are shorter than 2^31 bases): 32-bit address arithmetic on top of the
+    // array bases.  RIGHT: the 16 bytes that start with the byte of base s; LEFT: the 16 bytes that END with the
+    // byte of base s-1 (lz_lut_window shifts them so that this base becomes the top pair of byte 14).
+    const u32 st = RIGHT ? s_ + (u32)LZ_PAD2 : s_ - 1u + (u32)LZ_PAD2;
+    const u32 sq = st - (u32)diag;
+    const u32 back = RIGHT ? 0u : 15u;
+    raw.tv = lz_load16(P.t2 + ((st >> 2) - back)); raw.qv = lz_load16(P.q2 + ((sq >> 2) - back));
     if constexpr (SPECIAL) {
-        if (RIGHT) { raw.tm = lz_load16(P.tsp + ((u64)(s + LZ_PAD2) >> 3)); raw.qm = lz_load16(P.qsp + ((u64)(sq + LZ_PAD2) >> 3)); }
-        else       { raw.tm = lz_load16(P.tsp + ((u64)(s - 1 + LZ_PAD2) >> 3) - 14); raw.qm = lz_load16(P.qsp + ((u64)(sq - 1 + LZ_PAD2) >> 3) - 14); }
+        const u32 mback = RIGHT ? 0u : 14u;
+        raw.tm = lz_load16(P.tsp + ((st >> 3) - mback)); raw.qm = lz_load16(P.qsp + ((sq >> 3) - mback));
     }
 }
 // 64 mask bits of one sequence from the 16 bytes lz_lut_fetch loaded: RIGHT: bit j = base s+j; LEFT: bit 63-j = base s-1-j
@@ -108,7 +105,7 @@ LZ_HD u64 lz_lut_mask64(const LzVec16& v, s64 s)
     return ((u64)lz_alignbit(v.w[3], v.w[2], k) << 32) | lz_alignbit(v.w[2], v.w[1], k);
 }
 
-// One 16-byte window (up to 60 bases = 15 groups) of one scan.  lut = the table (lzh_lut_build).
+// One 16-byte window (up to 60 bases = 15 groups) of one scan.  lut = both tables (lzh_lut_build).
 // LIMCHK == false: the caller guarantees 60 plain bases (st.room >= 60, no special byte in reach): the limit tests
 // drop out of the straight-line part and the stopping group needs no general walk.
 // On return st.alive says whether the scan goes on into the next window.
@@ -116,17 +113,21 @@ template <bool RIGHT, bool SPECIAL, bool LIMCHK>
 LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& st, const LzLutRaw<SPECIAL>& raw)
 {
     const s32 X = P.xdrop;
-    const s64 s = (s64)st.s, sq = s - (s64)diag;
+    const LzLutEntry* const tab = lut + (RIGHT ? 0 : LZ_LUT_ENTRIES);
+    const u32 spad = RIGHT ? st.s + (u32)LZ_PAD2 : st.s - 1u + (u32)LZ_PAD2, qpad = spad - (u32)diag;
     u32 tw[4], qw[4];
     {
-        const u32 a = RIGHT ? 2u * (u32)((u64)(s + LZ_PAD2) & 3u) : 2u * (3u - (u32)((u64)(s - 1 + LZ_PAD2) & 3u));
-        const u32 b = RIGHT ? 2u * (u32)((u64)(sq + LZ_PAD2) & 3u) : 2u * (3u - (u32)((u64)(sq - 1 + LZ_PAD2) & 3u));
+        // RIGHT: base s to bit 0.  LEFT: base s-1 (pair 60 + r of the 64 loaded) to pair 59, the top of byte 14: a
+        // right shift of r + 1 pairs, never zero.
+        const u32 a = RIGHT ? 2u * (spad & 3u) : 2u * (spad & 3u) + 2u;
+        const u32 b = RIGHT ? 2u * (qpad & 3u) : 2u * (qpad & 3u) + 2u;
         tw[0] = lz_alignbit(raw.tv.w[1], raw.tv.w[0], a); tw[1] = lz_alignbit(raw.tv.w[2], raw.tv.w[1], a); tw[2] = lz_alignbit(raw.tv.w[3], raw.tv.w[2], a); tw[3] = raw.tv.w[3] >> a;
         qw[0] = lz_alignbit(raw.qv.w[1], raw.qv.w[0], b); qw[1] = lz_alignbit(raw.qv.w[2], raw.qv.w[1], b); qw[2] = lz_alignbit(raw.qv.w[3], raw.qv.w[2], b); qw[3] = raw.qv.w[3] >> b;
     }
     u32 lim = st.room < (u32)LZ_LUT_WIN_B ? st.room : (u32)LZ_LUT_WIN_B;
     bool soft = false;
     if constexpr (SPECIAL) {
+        const s64 s = (s64)st.s, sq = s - (s64)diag;
         const u64 sm = lz_lut_mask64<RIGHT>(raw.tm, s) | lz_lut_mask64<RIGHT>(raw.qm, sq);
         const u32 nsp = sm ? (RIGHT ? lz_ctz64(sm) : lz_clz64(sm)) : 64u;
         if (nsp < lim) { soft = true; lim = nsp; }
@@ -136,62 +137,61 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     LZ_UNROLL_ALL
     for (int k = 0; k < 4; k++) {
         xw[k] = tw[k] ^ qw[k];
-        const u32 p = tw[k] & 0x55555555u;
-        const u32 u = (p | (p >> 1)) & 0x33333333u;
+        const u32 u = (tw[k] & 0x11111111u) | ((tw[k] >> 1) & 0x22222222u);
         wc[k] = (u | (u >> 2)) & 0x0F0F0F0Fu;
     }
     // ---- the straight-line part: every group whose four bases lie inside the limit, until the margin test fails
     const u32 glim = lim >> 2;
     s32 run = st.run, m = run - st.best + X;
+    u32 np = 0, fsc = 0;                                        // groups passed; the scores of the group the walk stopped in
 #if !defined(LZ_LUT_NO_EARLY_EXIT) && defined(__HIP_DEVICE_COMPILE__)
     // a lane leaves the straight-line part at its first failing group (divergent exit: the lane is masked off in
     // EXEC, nothing has to be frozen with selects: 7 instead of 11 VALU instructions per group; measured
     // k_scan_hits 81 -> 77 ms per step against the select form below, which the host build keeps)
-    u32 np = 0;
     {
+        // the entries of even / odd groups in two variables that take turns: the one the walk stopped on is still
+        // there after the exit (no per-group copy of it)
+#define LZ_LUT_ENTRY_OF(g_) tab[lz_byte_pair(wc[LZ_LUT_GBYTE(RIGHT, g_) >> 2], xw[LZ_LUT_GBYTE(RIGHT, g_) >> 2], LZ_LUT_GBYTE(RIGHT, g_) & 3)]
+        LzLutEntry ea = LZ_LUT_ENTRY_OF(0), eb = ea;
         LZ_UNROLL_ALL
-        for (int b = 0; b < 4; b++) {
-            LzLutEntry eb[4];
-            LZ_UNROLL_ALL
-            for (int k = 0; k < 4; k++) if (4 * b + k < LZ_LUT_WIN_G) eb[k] = lut[lz_byte_pair(wc[b], xw[b], k)];
-            LZ_UNROLL_ALL
-            for (int k = 0; k < 4; k++) {
-                const int g = 4 * b + k;
-                if (g < LZ_LUT_WIN_G) {
-                    if (m < (s32)(eb[k].ab & 0xFFFFu)) goto groups_done;
-                    if (LIMCHK && (u32)g >= glim) goto groups_done;
-                    const s32 bq = (s32)eb[k].ab >> 16;
-                    m = lz_sdot4(eb[k].sc, m < bq ? m : bq);
-                    run = lz_sdot4(eb[k].sc, run);
-                    np = (u32)g + 1u;
-                }
+        for (int g = 0; g < LZ_LUT_WIN_G; g += 2) {
+            if (g + 1 < LZ_LUT_WIN_G) eb = LZ_LUT_ENTRY_OF(g + 1);
+            if (m < (s32)(ea.ab & 0xFFFFu)) goto groups_done;
+            if (LIMCHK && (u32)g >= glim) goto groups_done;
+            { const s32 bq = (s32)ea.ab >> 16; m = lz_sdot4(ea.sc, m < bq ? m : bq); run = lz_sdot4(ea.sc, run); np = (u32)g + 1u; }
+            if (g + 1 < LZ_LUT_WIN_G) {
+                if (g + 2 < LZ_LUT_WIN_G) ea = LZ_LUT_ENTRY_OF(g + 2);
+                if (m < (s32)(eb.ab & 0xFFFFu)) goto groups_done;
+                if (LIMCHK && (u32)(g + 1) >= glim) goto groups_done;
+                { const s32 bq = (s32)eb.ab >> 16; m = lz_sdot4(eb.sc, m < bq ? m : bq); run = lz_sdot4(eb.sc, run); np = (u32)g + 2u; }
             }
         }
+        groups_done:
+        fsc = (np & 1u) ? eb.sc : ea.sc;
+#undef LZ_LUT_ENTRY_OF
     }
-groups_done:
 #else
-    bool dead = false;
-    u32 nd = 0;                                                 // groups NOT passed (dead is sticky)
-    LZ_UNROLL_ALL
-    for (int g = 0; g < LZ_LUT_WIN_G; g++) {
-        const LzLutEntry e = lut[lz_byte_pair(wc[g >> 2], xw[g >> 2], g & 3)];
-        dead = dead | (m < (s32)(e.ab & 0xFFFFu));
-        if (LIMCHK) dead = dead | ((u32)g >= glim);
-        const s32 bq = (s32)e.ab >> 16;
-        const s32 t = lz_sdot4(e.sc, m < bq ? m : bq);
-        const s32 r2 = lz_sdot4(e.sc, run);
-        m = dead ? m : t; run = dead ? run : r2; nd += dead ? 1u : 0u;
+    {
+        bool dead = false;
+        LZ_UNROLL_ALL
+        for (int g = 0; g < LZ_LUT_WIN_G; g++) {
+            const int by = LZ_LUT_GBYTE(RIGHT, g);
+            const LzLutEntry e = tab[lz_byte_pair(wc[by >> 2], xw[by >> 2], by & 3)];
+            if (!dead) fsc = e.sc;
+            dead = dead | (m < (s32)(e.ab & 0xFFFFu));
+            if (LIMCHK) dead = dead | ((u32)g >= glim);
+            const s32 bq = (s32)e.ab >> 16;
+            const s32 t = lz_sdot4(e.sc, m < bq ? m : bq);
+            const s32 r2 = lz_sdot4(e.sc, run);
+            m = dead ? m : t; run = dead ? run : r2; np += dead ? 0u : 1u;
+        }
     }
-    const u32 np = (u32)LZ_LUT_WIN_G - nd;
 #endif
     // ---- the group the straight-line part stopped in (np < 15), base by base: the reference's loop
     u32 r = 0;
     if (np < (u32)LZ_LUT_WIN_G) { r = lim - 4u * np; if (r > 4u) r = 4u; }       // 4: the margin test failed inside the limit
     s32 best = run - m + X;
-    const u32 byte = np & 15u, wsel = byte >> 2, bsh = 8u * (byte & 3u);
-    const u32 xsel = wsel == 0 ? xw[0] : wsel == 1 ? xw[1] : wsel == 2 ? xw[2] : xw[3];
-    const u32 csel = wsel == 0 ? wc[0] : wsel == 1 ? wc[1] : wsel == 2 ? wc[2] : wc[3];
-    const u32 sc = lut[(((csel >> bsh) & 0xFFu) << 8) | ((xsel >> bsh) & 0xFFu)].sc;
+    const u32 sc = fsc;
     bool stop = false; u32 j = 0;
     if (LIMCHK) {
         LZ_UNROLL_ALL
@@ -205,13 +205,11 @@ groups_done:
         }
     } else if (r) {
         // the margin test failed in this group: the scan stops on its first base that takes the margin below zero,
-        // and its best does not move (a group cannot gain and then lose more than xDrop)
-        const s32 p1 = m + (s32)(int8_t)sc, p2 = p1 + (s32)(int8_t)(sc >> 8), p3 = p2 + (s32)(int8_t)(sc >> 16), p4 = p3 + (s32)(int8_t)(sc >> 24);
-        const bool a1 = p1 >= 0, a2 = a1 && p2 >= 0, a3 = a2 && p3 >= 0;
-        j = 1u + (a1 ? 1u : 0u) + (a2 ? 1u : 0u) + (a3 ? 1u : 0u);
-        stop = !(a3 && p4 >= 0);
-        const s32 q1 = (s32)(int8_t)sc, q2 = q1 + (s32)(int8_t)(sc >> 8), q3 = q2 + (s32)(int8_t)(sc >> 16);
-        run += j == 1 ? q1 : j == 2 ? q2 : j == 3 ? q3 : q3 + (s32)(int8_t)(sc >> 24);
+        // and its best does not move (a group cannot gain and then lose more than xDrop); run no longer matters
+        const s32 p1 = lz_sdot4m(sc, 0x00000001u, m), p2 = lz_sdot4m(sc, 0x00000101u, m), p3 = lz_sdot4m(sc, 0x00010101u, m), p4 = lz_sdot4(sc, m);
+        const s32 q2 = p1 | p2, q3 = q2 | p3;                   // sign bit: some prefix so far is negative
+        j = 4u + (u32)(p1 >> 31) + (u32)(q2 >> 31) + (u32)(q3 >> 31);
+        stop = (q3 | p4) < 0;
     }
     st.run = run; st.best = best;
     st.used += 4u * np + j;

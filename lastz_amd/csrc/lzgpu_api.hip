@@ -533,6 +533,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     const int nsets = overlap ? (int)std::min<size_t>(chunks.size() ? chunks.size() : 1, LZ_SETS) : 1;
     if (max_chunk) {
         if ((rc = c.keys[0].ensure((size_t)max_chunk * 8))) return rc;
+        if ((rc = c.bins[0].ensure((size_t)max_chunk + 64))) return rc;      // k_fill_hits writes a partition byte per hit on every path (the plain-hit path included)
         if (a->extend) {
             const size_t ntiles = (size_t)((max_chunk + LZ_PP_TILE_HOST - 1) / LZ_PP_TILE_HOST), nblocks = (ntiles + 255) / 256;
             for (int k = 0; k < nsets; k++) {
@@ -569,7 +570,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (mode < 2) {
             static std::vector<LzLutEntry> lut_host; static s32 lut_m4[16]; static s32 lut_x = -1;
             if (lut_x != a->xdrop || memcmp(lut_m4, M4, sizeof(M4)) != 0 || !c.lut.p || lut_host.empty()) {
-                lut_host.resize(LZ_LUT_ENTRIES);
+                lut_host.resize(LZ_LUT_TOTAL);
                 lzh_lut_build(M4, a->xdrop, lut_host.data());
                 if ((rc = c.lut.ensure(lut_host.size() * sizeof(LzLutEntry)))) return rc;
                 memcpy(lut_m4, M4, sizeof(M4)); lut_x = a->xdrop;

@@ -616,10 +616,44 @@ static_assert(sizeof(LzScanTask) == 64, "LzScanTask: one 64-byte line per task")
 #define LZ_SC_TPB 512
 struct LzScanShared {
     union {
-        LzLutEntry lut[LZ_LUT_ENTRIES];                                 // MODE 0/1: the look-up table (32 KiB)
+        LzLutEntry lut[LZ_LUT_TOTAL];                                   // MODE 0/1: the two look-up tables (64 KiB)
         struct { s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64]; } bc;    // MODE 2: the byte-code scans' tables
     };
 };
+
+// one round of k_scan_hits<0/1>: both scans' first windows of the hit `key`, whose windows (rawl, rawr) are loaded.
+// MODE 0 heads run without limit tests: a side with less than 60 bases of room is left to k_scan_tasks.
+template <bool SP>
+__device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzLutParams& Q, const LzLutEntry* lut, u64 key, bool valid,
+                                              const LzLutRaw<SP>& rawl, const LzLutRaw<SP>& rawr, u32 idx, u32 lane,
+                                              u32* __restrict__ summ, LzScanTask* __restrict__ my_tasks, u32& my_n, u32 region_cap)
+{
+    constexpr bool HLIM = SP;
+    s32 diag; LzLutScan L, R;
+    lz_lut_init(key, P.tlen, P.qlen, diag, L, R);
+    if (!valid) { L.alive = 0; R.alive = 0; }
+    const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
+    lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr);
+    const bool more = valid && (L.alive == 1 || R.alive == 1);
+    const u64 mm = __ballot(more);
+    bool queued = false;
+    if (mm) {                                                    // (wave-uniform)
+        const u32 slot = my_n + (u32)__popcll(mm & ((1ull << lane) - 1ull));
+        if (more && slot < region_cap) {                         // (a full region leaves the scan "alive": the hit becomes SLOW)
+            LzScanTask t; t.idx = idx; t.diag = diag; t.L = L; t.R = R;
+            my_tasks[slot] = t; queued = true;
+        }
+        my_n += (u32)__popcll(mm);
+    }
+    if (valid && !queued) summ[idx] = lz_lut_summary(L, R, P.min_score);
+}
+template <bool SP>
+__device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzLutRaw<SP>& rawl, LzLutRaw<SP>& rawr)
+{
+    const u32 pos2 = (u32)key, pos1 = pos2 + (u32)(key >> 32);
+    const s32 diag = (s32)(u32)(key >> 32);
+    lz_lut_fetch<false, SP>(Q, pos1, diag, rawl); lz_lut_fetch<true, SP>(Q, pos1, diag, rawr);
+}
 
 template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
 __global__ void __launch_bounds__(LZ_SC_TPB)
@@ -629,7 +663,7 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
 {
     __shared__ LzScanShared sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_ENTRIES; k += LZ_SC_TPB) sh.lut[k] = lut_g[k]; }
+    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_TOTAL; k += LZ_SC_TPB) sh.lut[k] = lut_g[k]; }
     else {
         for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_SC_TPB) sh.bc.tab[k] = score_tab_g[k];
         if (tid < 64) sh.bc.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
@@ -637,57 +671,56 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
     __syncthreads();
     const LzLutEntry* lut = sh.lut;
     constexpr bool SP = MODE == 1;
-    constexpr bool HLIM = SP;                        // MODE 0 heads run without limit tests: a side with less than 60 bases of room becomes a task
     constexpr u32 SPAN = 64u * LZ_SC_ROUNDS;
+    static_assert(LZ_SC_ROUNDS == 4, "the round pipeline below is written out for four rounds per span");
     const u64 nspans = (n + SPAN - 1) / SPAN, wstride = (u64)gridDim.x * (LZ_SC_TPB / 64);
     // the tasks of a wave go to the wave's own region of the list: no atomics, the count is written once at the end
     const u32 region = blockIdx.x * (LZ_SC_TPB / 64) + w;
     LzScanTask* const my_tasks = tasks + (size_t)region * region_cap;
     u32 my_n = 0;
-    for (u64 span = (u64)blockIdx.x * (LZ_SC_TPB / 64) + w; span < nspans; span += wstride) {
-        const u64 base = span * SPAN;
-        const u32 span_n = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
+    u64 span = (u64)blockIdx.x * (LZ_SC_TPB / 64) + w;
+    if (MODE == 2) {
+        for (; span < nspans; span += wstride) {
+            const u64 base = span * SPAN;
+            const u32 span_n = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
+#pragma unroll 1
+            for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
+                const u32 li = r * 64u + lane;
+                if (li < span_n) summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, keys[base + li]);
+            }
+        }
+    } else if (span < nspans) {
+        // A wave takes 256 consecutive hits (a span), 64 per round.  The windows of a round are requested one round
+        // ahead into two register sets that take turns (no copies), the next span's keys two rounds ahead and its
+        // first windows during the span's last round: every load has a round of arithmetic to hide behind.
+        auto load_keys = [&](u64 sp, u64& a0, u64& a1, u64& a2, u64& a3) {
+            const u64 base = sp * SPAN;
+            const u32 sn = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
+            a0 = (lane < sn) ? keys[base + lane] : 0ull;               a1 = (lane + 64u < sn) ? keys[base + lane + 64u] : 0ull;
+            a2 = (lane + 128u < sn) ? keys[base + lane + 128u] : 0ull; a3 = (lane + 192u < sn) ? keys[base + lane + 192u] : 0ull;
+        };
         u64 k0, k1, k2, k3;
-        k0 = (lane < span_n) ? keys[base + lane] : 0ull;               k1 = (lane + 64u < span_n) ? keys[base + lane + 64u] : 0ull;
-        k2 = (lane + 128u < span_n) ? keys[base + lane + 128u] : 0ull; k3 = (lane + 192u < span_n) ? keys[base + lane + 192u] : 0ull;
-        if (MODE == 2) {
+        load_keys(span, k0, k1, k2, k3);
+        LzLutRaw<SP> al, ar, bl, br;
+        lz_scan_fetch<SP>(Q, k0, al, ar);
 #pragma unroll 1
-            for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
-                const u32 li = r * 64u + lane;
-                if (li < span_n) summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, k0);
-                const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
-            }
-        } else {
-            s32 diag; LzLutScan L, R; LzLutRaw<SP> rawl, rawr;
-            lz_lut_init(k0, P.tlen, P.qlen, diag, L, R);
-            lz_lut_fetch<false, SP>(Q, L.s, diag, rawl); lz_lut_fetch<true, SP>(Q, R.s, diag, rawr);
-#pragma unroll 1
-            for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
-                const u32 li = r * 64u + lane;
-                const bool valid = li < span_n;
-                // the next round's windows
-                s32 ndiag; LzLutScan NL, NR; LzLutRaw<SP> nrawl, nrawr;
-                lz_lut_init(k1, P.tlen, P.qlen, ndiag, NL, NR);
-                if (r + 1 < LZ_SC_ROUNDS) { lz_lut_fetch<false, SP>(Q, NL.s, ndiag, nrawl); lz_lut_fetch<true, SP>(Q, NR.s, ndiag, nrawr); }
-                else { nrawl = rawl; nrawr = rawr; }
-                if (!valid) { L.alive = 0; R.alive = 0; }
-                const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
-                lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr);
-                const bool more = valid && (L.alive == 1 || R.alive == 1);
-                const u64 mm = __ballot(more);
-                bool queued = false;
-                if (mm) {                                                // (wave-uniform)
-                    const u32 slot = my_n + (u32)__popcll(mm & ((1ull << lane) - 1ull));
-                    if (more && slot < region_cap) {                     // (a full region leaves the scan "alive": the hit becomes SLOW)
-                        LzScanTask t; t.idx = (u32)(base + li); t.diag = diag; t.L = L; t.R = R;
-                        my_tasks[slot] = t; queued = true;
-                    }
-                    my_n += (u32)__popcll(mm);
-                }
-                if (valid && !queued) summ[base + li] = lz_lut_summary(L, R, P.min_score);
-                const u64 t = k0; k0 = k1; k1 = k2; k2 = k3; k3 = t;
-                diag = ndiag; L = NL; R = NR; rawl = nrawl; rawr = nrawr;
-            }
+        for (;;) {
+            const u64 base = span * SPAN;
+            const u32 span_n = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
+            const u32 ib = (u32)base + lane;                     // (hit indices inside a chunk are 32-bit: lzgpu_set_hit_capacity)
+            const bool more_spans = span + wstride < nspans;
+            u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+            lz_scan_fetch<SP>(Q, k1, bl, br);
+            lz_scan_round<SP>(P, Q, lut, k0, lane < span_n, al, ar, ib, lane, summ, my_tasks, my_n, region_cap);
+            if (more_spans) load_keys(span + wstride, n0, n1, n2, n3);
+            lz_scan_fetch<SP>(Q, k2, al, ar);
+            lz_scan_round<SP>(P, Q, lut, k1, lane + 64u < span_n, bl, br, ib + 64u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_fetch<SP>(Q, k3, bl, br);
+            lz_scan_round<SP>(P, Q, lut, k2, lane + 128u < span_n, al, ar, ib + 128u, lane, summ, my_tasks, my_n, region_cap);
+            if (more_spans) lz_scan_fetch<SP>(Q, n0, al, ar);
+            lz_scan_round<SP>(P, Q, lut, k3, lane + 192u < span_n, bl, br, ib + 192u, lane, summ, my_tasks, my_n, region_cap);
+            if (!more_spans) break;
+            span += wstride; k0 = n0; k1 = n1; k2 = n2; k3 = n3;
         }
     }
     if (lane == 0) n_tasks[region] = my_n < region_cap ? my_n : region_cap;
@@ -698,8 +731,8 @@ __global__ void __launch_bounds__(256)
 k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut_g, const LzScanTask* __restrict__ tasks,
              const u32* __restrict__ n_tasks, u32 n_regions, u32 region_cap, u32* __restrict__ summ)
 {
-    __shared__ LzLutEntry lut[LZ_LUT_ENTRIES];
-    for (u32 k = threadIdx.x; k < LZ_LUT_ENTRIES; k += 256) lut[k] = lut_g[k];
+    __shared__ LzLutEntry lut[LZ_LUT_TOTAL];
+    for (u32 k = threadIdx.x; k < LZ_LUT_TOTAL; k += 256) lut[k] = lut_g[k];
     __syncthreads();
     constexpr bool SP = MODE == 1;
     for (u32 region = blockIdx.x; region < n_regions; region += gridDim.x) {
