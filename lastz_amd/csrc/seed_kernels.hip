@@ -750,10 +750,18 @@ k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut
 // keys + summaries -> records in their partitions.  One workgroup per tile of k_hist; a wave owns 256 consecutive
 // hits (64 per round), so ranks by (wave, round, lane) follow the discovery order.
 struct LzPartShared {
-    u64 stage[LZ_PP_TILE];                           // the tile's records, ordered by partition (the partition rides in bits 55..62)
+    union {
+        u64 stage[LZ_PP_TILE];                       // the tile's records, ordered by partition (the partition rides in bits 55..62)
+        u64 bm[LZ_PP_WAVES][LZ_NBIN];                // BM: peer bitmaps of the round in flight (all zero again before stage[] is written)
+    };
     u32 wcnt[LZ_PP_WAVES][LZ_NBIN];                  // per wave and partition: records / running offset inside the partition
     u32 tstart[LZ_NBIN + 1], gbase[LZ_NBIN], wtot[4];
 };
+// BM == false: round 2's ranks (LDS atomics count, an 8-ballot match ranks: half of the kernel's 161 VALU instructions
+// per hit).  BM == true: the lanes of a round that hold the same partition find each other through a 64-bit bitmap
+// in LDS (atomic OR of 1 << lane, one read; the result does not depend on the order of the ORs), which gives rank
+// and count in one pass and leaves the per-wave totals behind -- no separate counting pass, no ballots.
+template <bool BM>
 __global__ void __launch_bounds__(LZ_PP_TPB)
 k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
             const u32* __restrict__ hist, const u32* __restrict__ part, u64* __restrict__ recs)
@@ -763,7 +771,7 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
     const u32 tile = blockIdx.x;
     const u64 base = (u64)tile * LZ_PP_TILE;
     const u32 tile_n = (n - base < (u64)LZ_PP_TILE) ? (u32)(n - base) : (u32)LZ_PP_TILE;
-    for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN; k += LZ_PP_TPB) (&sh.wcnt[0][0])[k] = 0;
+    for (u32 k = tid; k < LZ_PP_WAVES * LZ_NBIN; k += LZ_PP_TPB) { (&sh.wcnt[0][0])[k] = 0; if (BM) (&sh.bm[0][0])[k] = 0ull; }
     const u32 l0 = w * (64u * LZ_PP_ROUNDS) + lane;
     u64 kk[LZ_PP_ROUNDS]; u32 ss[LZ_PP_ROUNDS];
 #pragma unroll
@@ -773,8 +781,23 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
         ss[r] = v ? summ[base + l0 + 64u * r] : 0u;
     }
     __syncthreads();
+    u32 slot[BM ? LZ_PP_ROUNDS : 1];
+    if (BM) {
+        // (each wave works on its own rows of bm / wcnt: LDS operations of one wave execute in order)
 #pragma unroll
-    for (u32 r = 0; r < LZ_PP_ROUNDS; r++) if (l0 + 64u * r < tile_n) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(kk[r])], 1u);
+        for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
+            const bool valid = l0 + 64u * r < tile_n;
+            const u32 bin = LZ_KEY_BIN(kk[r]);
+            if (valid) atomicOr((unsigned long long*)&sh.bm[w][bin], 1ull << lane);
+            const u64 peers = valid ? sh.bm[w][bin] : 0ull;
+            const u32 old = valid ? sh.wcnt[w][bin] : 0u;
+            if (valid && (peers >> lane) == 1ull) { sh.wcnt[w][bin] = old + (u32)__popcll(peers); sh.bm[w][bin] = 0ull; }   // the highest peer
+            slot[r] = old + (u32)__popcll(peers & ((1ull << lane) - 1ull));
+        }
+    } else {
+#pragma unroll
+        for (u32 r = 0; r < LZ_PP_ROUNDS; r++) if (l0 + 64u * r < tile_n) atomicAdd(&sh.wcnt[w][LZ_KEY_BIN(kk[r])], 1u);
+    }
     __syncthreads();
     // per-partition counts chained in wave order (= discovery order) ...
     u32 tot = 0;
@@ -792,11 +815,15 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
     for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
         const bool valid = l0 + 64u * r < tile_n;
         const u32 bin = LZ_KEY_BIN(kk[r]);
-        u32 rank, count; bool last;
-        lz_match8(bin, valid, lane, rank, count, last);
-        const u32 old = sh.wcnt[w][bin];
-        if (valid && last) sh.wcnt[w][bin] = old + count;
-        if (valid) sh.stage[sh.tstart[bin] + old + rank] = lz_hit_record(kk[r], ss[r]) | ((u64)bin << 55);
+        if (BM) {
+            if (valid) sh.stage[sh.tstart[bin] + sh.wcnt[w][bin] + slot[r]] = lz_hit_record(kk[r], ss[r]) | ((u64)bin << 55);
+        } else {
+            u32 rank, count; bool last;
+            lz_match8(bin, valid, lane, rank, count, last);
+            const u32 old = sh.wcnt[w][bin];
+            if (valid && last) sh.wcnt[w][bin] = old + count;
+            if (valid) sh.stage[sh.tstart[bin] + old + rank] = lz_hit_record(kk[r], ss[r]) | ((u64)bin << 55);
+        }
     }
     __syncthreads();
     for (u32 k = tid; k < tile_n; k += LZ_PP_TPB) {
@@ -863,7 +890,9 @@ int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, co
     if (n == 0) return 0;
     const u32 ntiles = (u32)((n + LZ_PP_TILE - 1) / LZ_PP_TILE);
     c.timer.begin("k_partition", st);
-    hipLaunchKernelGGL(k_partition, dim3(ntiles), dim3(LZ_PP_TPB), 0, st, keys, c.summ[set].as<u32>(), n, hist, part, recs);
+    static const bool ballots = getenv("LZGPU_PARTITION_BALLOTS") != nullptr;  // A/B aid: round 2's ballot-match ranks
+    if (ballots) hipLaunchKernelGGL(k_partition<false>, dim3(ntiles), dim3(LZ_PP_TPB), 0, st, keys, c.summ[set].as<u32>(), n, hist, part, recs);
+    else         hipLaunchKernelGGL(k_partition<true>, dim3(ntiles), dim3(LZ_PP_TPB), 0, st, keys, c.summ[set].as<u32>(), n, hist, part, recs);
     c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -1125,11 +1154,218 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Phase B, pipelined (round 3).  Same job as k_settle, one workgroup of 1024 lanes per partition, but the 16 waves
+// have two roles and meet at ONE barrier per tile:
+//   waves 0..3   walkers: lane l of wave w walks bucket 64 w + l of the tile that was placed during the previous
+//                interval -- all 64 lanes of a walking wave are busy (k_settle walked with 16 lanes of every wave:
+//                the walk was bound by VALU issue, 4 x the instructions it needs);
+//   waves 4..15  sorters: while tile t is walked they place tile t+1 (offsets from the counts taken one interval
+//                earlier, each wave computing the 256 bucket bases for itself from the per-wave counts: no barrier
+//                between scan and placement) and count tile t+2 (ranks inside (wave, bucket)).
+// Ranks are deterministic: the lanes of a round that hold the same bucket find each other through a 64-bit
+// bitmap in LDS (atomic OR of 1 << lane, then a read: the set of peers is independent of the order in which the
+// hardware applies the ORs), rank = peers in lower lanes, and the highest peer adds the group to the wave's
+// running count.  k_settle took the rank from the return value of a same-address LDS atomic add and repaired
+// disorder after the fact; here no order is assumed anywhere.
+#define LZ_S2_TPB     1024
+#define LZ_S2_WALKW   4                                  // walking waves: 64 buckets each
+#define LZ_S2_SORTW   (LZ_S2_TPB / 64 - LZ_S2_WALKW)     // 12 sorting waves
+#define LZ_S2_ROUNDS  4                                  // records per sorter lane and tile
+#define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 3072
+struct LzSettle2Shared {
+    s32 tab[LZ_NCLASS * LZ_NCLASS];
+    u64 rec[2][LZ_S2_TILE + LZ_ST_BATCH];                // the placed tiles (bucket-major), two take turns
+    u64 bm[LZ_S2_SORTW][LZ_NBIN];                        // peer bitmaps of the round in flight (zero between rounds)
+    u32 cnt[2][LZ_S2_SORTW][LZ_NBIN];                    // records per (wave, bucket) of the tile being counted / placed
+    u32 woff[LZ_S2_SORTW][LZ_NBIN];                      // where wave w's records of bucket b start in the placed tile
+    u32 lbeg[2][LZ_NBIN], lcnt[2][LZ_NBIN];              // bucket lists of the placed tiles
+};
+__global__ void __launch_bounds__(LZ_S2_TPB)
+k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__ bin_base, u32* __restrict__ diag_end,
+          const s32* __restrict__ score_tab_g, LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap,
+          u64* __restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char lz_s2_smem[];
+    LzSettle2Shared& sh = *reinterpret_cast<LzSettle2Shared*>(lz_s2_smem);
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // wave-uniform, and the compiler knows it
+    const u32 part = blockIdx.x;
+    const u32 r0 = bin_base[part], r1 = bin_base[part + 1];
+    const u32 n = r1 - r0, ntiles = (n + LZ_S2_TILE - 1) / LZ_S2_TILE;
+    if (ntiles == 0) return;                                    // (uniform: nothing of this partition in the chunk)
+    for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_S2_TPB) sh.tab[k] = score_tab_g[k];
+    for (u32 k = tid; k < LZ_S2_SORTW * LZ_NBIN; k += LZ_S2_TPB) (&sh.bm[0][0])[k] = 0ull;
+    const bool walker = w < LZ_S2_WALKW;
+    const u32 sw = w - LZ_S2_WALKW;                             // sorter wave index (sorters only)
+
+    // ---- sorter pieces
+    u64 cx[LZ_S2_ROUNDS], nx[LZ_S2_ROUNDS];                     // records of the tile to place next / to count next
+    u32 cslot[LZ_S2_ROUNDS];
+    auto load_tile = [&](u32 tt, u64* x) {                      // (sorters) the wave's 256 records of tile tt, 64 per round
+#pragma unroll
+        for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) {
+            const u64 li = (u64)tt * LZ_S2_TILE + sw * (64u * LZ_S2_ROUNDS) + (u32)rr * 64u + lane;
+            x[rr] = (tt < ntiles && li < (u64)n) ? recs[(size_t)r0 + li] : ~0ull;       // ~0: no record
+        }
+    };
+    auto count_tile = [&](u32 tt, const u64* x, u32* slot) {    // ranks inside (wave, bucket) -> slot[], totals -> cnt[tt & 1][sw][]
+        u32* const row = sh.cnt[tt & 1u][sw];
+        reinterpret_cast<uint4*>(row)[lane] = make_uint4(0u, 0u, 0u, 0u);
+        u64* const bmr = sh.bm[sw];
+#pragma unroll
+        for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) {
+            const bool valid = x[rr] != ~0ull;
+            const u32 b = LZ_REC_LOW8(x[rr]);
+            if (valid) atomicOr((unsigned long long*)&bmr[b], 1ull << lane);
+            const u64 peers = valid ? bmr[b] : 0ull;
+            const u32 old = valid ? row[b] : 0u;
+            const u32 rank = (u32)__popcll(peers & ((1ull << lane) - 1ull));
+            if (valid && (peers >> lane) == 1ull) { row[b] = old + (u32)__popcll(peers); bmr[b] = 0ull; }   // the highest peer
+            slot[rr] = old + rank;
+        }
+    };
+    auto place_tile = [&](u32 tt, const u64* x, const u32* slot) {
+        // bucket bases of the tile: every sorter wave sums the 12 rows for its own use (lane l: buckets 4l .. 4l+3)
+        const u32 (*cn)[LZ_NBIN] = sh.cnt[tt & 1u];
+        uint4 tot = make_uint4(0u, 0u, 0u, 0u), pre = tot;
+#pragma unroll
+        for (u32 k = 0; k < LZ_S2_SORTW; k++) {
+            const uint4 v = reinterpret_cast<const uint4*>(cn[k])[lane];
+            if (k == sw) pre = tot;
+            tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        }
+        const u32 mine = tot.x + tot.y + tot.z + tot.w;
+        u32 inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
+        const u32 b0 = inc - mine, b1 = b0 + tot.x, b2 = b1 + tot.y, b3 = b2 + tot.z;
+        reinterpret_cast<uint4*>(sh.woff[sw])[lane] = make_uint4(b0 + pre.x, b1 + pre.y, b2 + pre.z, b3 + pre.w);
+        if (sw == 0) {
+            reinterpret_cast<uint4*>(sh.lbeg[tt & 1u])[lane] = make_uint4(b0, b1, b2, b3);
+            reinterpret_cast<uint4*>(sh.lcnt[tt & 1u])[lane] = tot;
+        }
+        u64* const dst = sh.rec[tt & 1u];
+#pragma unroll
+        for (int rr = 0; rr < LZ_S2_ROUNDS; rr++)
+            if (x[rr] != ~0ull) dst[sh.woff[sw][LZ_REC_LOW8(x[rr])] + slot[rr]] = x[rr];
+    };
+
+    // ---- the two roles run their own loops (the register allocator sees two disjoint sets of live values) and
+    // meet at the same barriers: 3 in the prologue, one per tile.  (s_barrier counts arrivals per wave, not places.)
+    __syncthreads();                                            // tab, bm
+    if (!walker) {
+        // prologue: tile 0 counted | tile 0 placed, tile 1 counted | then per interval t: tile t+1 placed, tile t+2 counted
+        load_tile(0, cx); load_tile(1, nx); count_tile(0, cx, cslot);
+        __syncthreads();
+        place_tile(0, cx, cslot);
+#pragma unroll
+        for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) cx[rr] = nx[rr];
+        load_tile(2, nx);
+        count_tile(1, cx, cslot);
+        __syncthreads();
+        for (u32 t = 0; t < ntiles; t++) {
+            if (t + 1 < ntiles) place_tile(t + 1, cx, cslot);
+#pragma unroll
+            for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) cx[rr] = nx[rr];
+            load_tile(t + 3, nx);                               // (past the last tile: no loads, "no record")
+            if (t + 2 < ntiles) count_tile(t + 2, cx, cslot);
+            __syncthreads();
+        }
+        return;
+    }
+    __syncthreads();
+    __syncthreads();
+    const u32 bucket = w * 64u + lane;                          // the lane's bucket
+    const u32 h = part * LZ_NBIN + bucket;
+    const u32 L = P.seed_len;
+    u32 dend = diag_end[h];
+    u64 n_ext = 0, n_bp = 0;
+    for (u32 t = 0; t < ntiles; t++) {
+        {
+            const u64* const rec = sh.rec[t & 1u];
+            u32 p = sh.lbeg[t & 1u][bucket]; const u32 end = p + sh.lcnt[t & 1u][bucket];
+            u32 ne = 0, nb = 0;
+            for (;;) {
+                // every lane settles records from their phase-A summaries, LZ_ST_BATCH at a time, until one needs a
+                // real extension
+                bool pending = false; u32 pp2 = 0, ppay = 0;
+                while (__ballot(p < end && !pending)) {         // straight-line batches: a lane that has stopped idles through selects
+                    u64 r[LZ_ST_BATCH];
+#pragma unroll
+                    for (int k = 0; k < LZ_ST_BATCH; k++) r[k] = rec[p + k];            // (reads past `end` stay inside rec[] and are not used)
+                    bool live = !pending;
+                    u32 np = 0;
+#pragma unroll
+                    for (int k = 0; k < LZ_ST_BATCH; k++) {
+                        const u32 p2 = LZ_REC_POS2(r[k]), pay = LZ_REC_PAYLOAD(r[k]);
+                        const bool in = live && (p + (u32)k < end);
+                        const bool drop = dend > p2 - L;                           // :1113
+                        const bool slow = LZ_REC_SLOW(r[k]) != 0 && !drop;
+                        const bool go = in && !slow;                               // the record is consumed here
+                        const bool fast = go && !drop;
+                        const u32 room = p2 - dend, dlo = pay & 0xFFu, dext = pay >> 8;
+                        const u32 extent = p2 + dext;                              // :2785
+                        ne += fast ? 1u : 0u;
+                        nb += fast ? (dlo < room ? dlo : room) + dext : 0u;        // :2818
+                        dend = (fast && extent > dend) ? extent : dend;
+                        np += go ? 1u : 0u;
+                        if (in && slow) { pending = true; pp2 = p2; ppay = pay; }
+                        live = go;
+                    }
+                    p += np;
+                }
+                u64 mask = __ballot(pending);
+                if (!mask) break;
+                while (mask) {                                  // the wave extends the pending hits, one at a time
+                    const int src = (int)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const u32 sp2 = (u32)__shfl((int)pp2, src), spay = (u32)__shfl((int)ppay, src), sdend = (u32)__shfl((int)dend, src);
+                    const u32 sh_ = part * LZ_NBIN + w * 64u + (u32)src;
+                    const s32 diag = (s32)((spay << 16) | sh_);
+                    const u32 pos1 = sp2 + (u32)diag;
+                    s32 stopl = (s32)sdend + diag;  if (stopl < 0) stopl = 0;                                     // :2612-2616
+                    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
+                    const LzCoopSide S = lz_coop_extend_wave(P, sh.tab, pos1, diag, stopl, stopr, lane);
+                    const u32 l_stop = (u32)__shfl((int)S.stop_pos, 0), l_bpos = (u32)__shfl((int)S.best_pos, 0); const s32 l_best = __shfl(S.best, 0);
+                    const u32 r_stop = (u32)__shfl((int)S.stop_pos, 32), r_bpos = (u32)__shfl((int)S.best_pos, 32); const s32 r_best = __shfl(S.best, 32);
+                    if ((int)lane == src) {
+                        ne++; nb += r_stop - l_stop;                                             // :2818
+                        const u32 extent = (u32)((s32)r_stop - diag);                            // :2785
+                        if (extent > dend) dend = extent;
+                        const s32 sim = l_best + r_best;
+                        if (sim >= P.min_score) {
+                            const u32 oslot = atomicAdd(out_count, 1u);
+                            if (oslot < out_cap) { LzHspRec o; o.seed_pos1 = pos1; o.seed_pos2 = sp2; o.end1 = r_bpos; o.length = r_bpos - l_bpos; o.score = sim; out[oslot] = o; }
+                        }
+                        p++;
+                    }
+                }
+            }
+            n_ext += ne; n_bp += nb;
+        }
+        __syncthreads();
+    }
+    diag_end[h] = dend;
+    for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
+    if (lane == 0) {
+        if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);
+        if (n_bp)  atomicAdd((unsigned long long*)&counters[1], (unsigned long long)n_bp);
+    }
+}
+
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
+    static const bool old_kernel = getenv("LZGPU_SETTLE_OLD") != nullptr;      // A/B aid: round 2's k_settle
     c.timer.begin("k_settle", s);
-    hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN * LZ_ST_SPLIT), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
+    if (old_kernel)
+        hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN * LZ_ST_SPLIT), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
+    else {
+        static bool attr_set = false;
+        if (!attr_set) { LZ_HIP(hipFuncSetAttribute((const void*)k_settle2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzSettle2Shared))); attr_set = true; }
+        hipLaunchKernelGGL(k_settle2, dim3(LZ_NBIN), dim3(LZ_S2_TPB), sizeof(LzSettle2Shared), s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
+    }
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;
