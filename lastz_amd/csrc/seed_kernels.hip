@@ -613,7 +613,7 @@ __device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
 // phases -- queue drain on two waves, ranks, write-out -- while holding the LDS and the wave slots the scans need.)
 struct LzScanTask { u32 idx; s32 diag; LzLutScan L, R; };
 static_assert(sizeof(LzScanTask) == 64, "LzScanTask: one 64-byte line per task");
-#define LZ_SC_TPB 512
+#define LZ_SC_TPB 512                                // k_scan_hits<1/2>, k_scan_tasks regions; k_scan_hits<0> picks its own size (TPB template parameter)
 struct LzScanShared {
     union {
         LzLutEntry lut[LZ_LUT_TOTAL];                                   // MODE 0/1: the two look-up tables (64 KiB)
@@ -653,19 +653,28 @@ __device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzL
     const u32 pos2 = (u32)key, pos1 = pos2 + (u32)(key >> 32);
     const s32 diag = (s32)(u32)(key >> 32);
     lz_lut_fetch<false, SP>(Q, pos1, diag, rawl); lz_lut_fetch<true, SP>(Q, pos1, diag, rawr);
+#if defined(LZ_EXP_NO_LEFT_TARGET)      // timing experiments only (results are wrong): what the random target fetches cost
+    rawl.tv = rawr.tv;
+#elif defined(LZ_EXP_NO_TARGET)
+    rawl.tv = rawl.qv; rawr.tv = rawr.qv;
+#elif defined(LZ_EXP_LOCAL_TARGET)
+    { LzLutParams Q2 = Q; Q2.t2 = Q.t2 + (size_t)(blockIdx.x & 7u) * 1048576u; const u32 p1 = pos1 & 0x3FFFFFu;     // every XCD inside its own 1 MiB of the target
+      lz_lut_fetch<false, SP>(Q2, p1, (s32)(p1 - pos2), rawl); lz_lut_fetch<true, SP>(Q2, p1, (s32)(p1 - pos2), rawr); }
+#endif
 }
 
-template <int MODE>      // 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
-__global__ void __launch_bounds__(LZ_SC_TPB)
+// TPB lanes per workgroup, WPE waves per SIMD the register allocation must allow (two workgroups share a CU's LDS)
+template <int MODE, int TPB, int WPE>      // MODE 0: LUT scans, no special bytes in either sequence; 1: LUT scans + special masks; 2: byte-code scans
+__global__ void __launch_bounds__(TPB, WPE)
 k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n,
             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
             u32* __restrict__ summ, LzScanTask* __restrict__ tasks, u32* __restrict__ n_tasks, u32 region_cap)
 {
     __shared__ LzScanShared sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_TOTAL; k += LZ_SC_TPB) sh.lut[k] = lut_g[k]; }
+    if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_TOTAL; k += TPB) sh.lut[k] = lut_g[k]; }
     else {
-        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_SC_TPB) sh.bc.tab[k] = score_tab_g[k];
+        for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += TPB) sh.bc.tab[k] = score_tab_g[k];
         if (tid < 64) sh.bc.tab8[tid] = score_tab_g[(tid >> 3) * LZ_NCLASS + (tid & 7)];
     }
     __syncthreads();
@@ -673,12 +682,12 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
     constexpr bool SP = MODE == 1;
     constexpr u32 SPAN = 64u * LZ_SC_ROUNDS;
     static_assert(LZ_SC_ROUNDS == 4, "the round pipeline below is written out for four rounds per span");
-    const u64 nspans = (n + SPAN - 1) / SPAN, wstride = (u64)gridDim.x * (LZ_SC_TPB / 64);
+    const u64 nspans = (n + SPAN - 1) / SPAN, wstride = (u64)gridDim.x * (TPB / 64);
     // the tasks of a wave go to the wave's own region of the list: no atomics, the count is written once at the end
-    const u32 region = blockIdx.x * (LZ_SC_TPB / 64) + w;
+    const u32 region = blockIdx.x * (TPB / 64) + w;
     LzScanTask* const my_tasks = tasks + (size_t)region * region_cap;
     u32 my_n = 0;
-    u64 span = (u64)blockIdx.x * (LZ_SC_TPB / 64) + w;
+    u64 span = (u64)blockIdx.x * (TPB / 64) + w;
     if (MODE == 2) {
         for (; span < nspans; span += wstride) {
             const u64 base = span * SPAN;
@@ -835,13 +844,20 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
 
 // grid of k_scan_hits for n hits, and the geometry of its task list: one region per wave, room for 1/8 of the
 // wave's hits + 64 (64 B each; the usual load is ~3 %); a hit that finds its region full is left to phase B
-static void lz_scan_geometry(LzCtx& c, u64 n, u32& grid, u32& n_regions, u32& region_cap)
+static int lz_scan_tpb(int mode)
 {
+    static const int env = getenv("LZGPU_SC_TPB") ? atoi(getenv("LZGPU_SC_TPB")) : 0;      // A/B aid: 512, 640, 768 or 1024
+    if (mode != 0) return LZ_SC_TPB;
+    return (env == 512 || env == 640 || env == 768 || env == 1024) ? env : 640;     // 640: five waves per SIMD at 89 VGPRs (512: 72.5, 640: 69.7, 768 with 8 spilled registers: 75.9 ms per step)
+}
+static void lz_scan_geometry(LzCtx& c, int mode, u64 n, u32& grid, u32& n_regions, u32& region_cap)
+{
+    const u32 wpg = (u32)lz_scan_tpb(mode) / 64u;
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
     static const u32 wgs = getenv("LZGPU_PP_WGS") ? (u32)atoi(getenv("LZGPU_PP_WGS")) : 2u;
-    const u64 nspans = (n + 64u * LZ_SC_ROUNDS - 1) / (64u * LZ_SC_ROUNDS), want = (nspans + LZ_SC_TPB / 64 - 1) / (LZ_SC_TPB / 64);
+    const u64 nspans = (n + 64u * LZ_SC_ROUNDS - 1) / (64u * LZ_SC_ROUNDS), want = (nspans + wpg - 1) / wpg;
     grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
-    n_regions = grid * (LZ_SC_TPB / 64);
+    n_regions = grid * wpg;
     region_cap = (u32)std::min<u64>(n / 8 / n_regions + 64, 1u << 20);
     static const char* force = getenv("LZGPU_TASK_REGION_CAP");  // test hook: tiny regions, so that hits find theirs full
     if (force && atoi(force) > 0) region_cap = (u32)atoi(force);
@@ -851,7 +867,7 @@ static void lz_scan_geometry(LzCtx& c, u64 n, u32& grid, u32& n_regions, u32& re
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n)
 {
     u32 grid, n_regions, region_cap; int rc;
-    lz_scan_geometry(c, max_n, grid, n_regions, region_cap);
+    lz_scan_geometry(c, mode, max_n, grid, n_regions, region_cap);
     if ((rc = c.summ[set].ensure((size_t)max_n * 4))) return rc;
     if (mode < 2 && (rc = c.scan_tasks[set].ensure((size_t)n_regions * region_cap * sizeof(LzScanTask)))) return rc;
     return c.scan_ntasks[set].ensure((size_t)n_regions * 4);
@@ -864,15 +880,23 @@ int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const Lz
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
     int rc;
     u32 grid, n_regions, task_cap;
-    lz_scan_geometry(c, n, grid, n_regions, task_cap);
+    lz_scan_geometry(c, mode, n, grid, n_regions, task_cap);
     if ((rc = c.summ[set].ensure((size_t)n * 4))) return rc;
     if (mode < 2 && (rc = c.scan_tasks[set].ensure((size_t)n_regions * task_cap * sizeof(LzScanTask)))) return rc;
     if ((rc = c.scan_ntasks[set].ensure((size_t)n_regions * 4))) return rc;
     u32* summ = c.summ[set].as<u32>(); LzScanTask* tasks = c.scan_tasks[set].as<LzScanTask>(); u32* ntk = c.scan_ntasks[set].as<u32>();
     c.timer.begin("k_scan_hits", st);
-    if (mode == 0)      hipLaunchKernelGGL(k_scan_hits<0>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
-    else if (mode == 1) hipLaunchKernelGGL(k_scan_hits<1>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
-    else                hipLaunchKernelGGL(k_scan_hits<2>, dim3(grid), dim3(LZ_SC_TPB), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap);
+    const int tpb = lz_scan_tpb(mode);
+#define LZ_SCAN_LAUNCH(M_, T_, W_) hipLaunchKernelGGL((k_scan_hits<M_, T_, W_>), dim3(grid), dim3(T_), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap)
+    if (mode == 0) {
+        if (tpb == 640)       LZ_SCAN_LAUNCH(0, 640, 5);
+        else if (tpb == 768)  LZ_SCAN_LAUNCH(0, 768, 6);
+        else if (tpb == 1024) LZ_SCAN_LAUNCH(0, 1024, 8);
+        else                  LZ_SCAN_LAUNCH(0, 512, 4);
+    }
+    else if (mode == 1) LZ_SCAN_LAUNCH(1, LZ_SC_TPB, 4);
+    else                LZ_SCAN_LAUNCH(2, LZ_SC_TPB, 4);
+#undef LZ_SCAN_LAUNCH
     c.timer.end(st);
     LZ_HIP(hipGetLastError());
     if (mode < 2) {
@@ -1169,9 +1193,13 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
 // running count.  k_settle took the rank from the return value of a same-address LDS atomic add and repaired
 // disorder after the fact; here no order is assumed anywhere.
 #define LZ_S2_TPB     1024
-#define LZ_S2_WALKW   4                                  // walking waves: 64 buckets each
+#ifndef LZ_S2_WALKW
+#define LZ_S2_WALKW   4                                  // walking waves: 256 / LZ_S2_WALKW buckets each
+#endif
 #define LZ_S2_SORTW   (LZ_S2_TPB / 64 - LZ_S2_WALKW)     // 12 sorting waves
-#define LZ_S2_ROUNDS  4                                  // records per sorter lane and tile
+#ifndef LZ_S2_ROUNDS
+#define LZ_S2_ROUNDS  6                                  // records per sorter lane and tile (3: 26.7, 4: 24.6, 6: 22.8 ms per step)
+#endif
 #define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 3072
 struct LzSettle2Shared {
     s32 tab[LZ_NCLASS * LZ_NCLASS];
@@ -1276,15 +1304,17 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
     }
     __syncthreads();
     __syncthreads();
-    const u32 bucket = w * 64u + lane;                          // the lane's bucket
+    constexpr u32 BPW = LZ_NBIN / LZ_S2_WALKW;                   // buckets (= walking lanes) per walking wave
+    const bool wl = lane < BPW;
+    const u32 bucket = (w * BPW + lane) & (LZ_NBIN - 1);        // the lane's bucket
     const u32 h = part * LZ_NBIN + bucket;
     const u32 L = P.seed_len;
-    u32 dend = diag_end[h];
+    u32 dend = wl ? diag_end[h] : 0u;
     u64 n_ext = 0, n_bp = 0;
     for (u32 t = 0; t < ntiles; t++) {
         {
             const u64* const rec = sh.rec[t & 1u];
-            u32 p = sh.lbeg[t & 1u][bucket]; const u32 end = p + sh.lcnt[t & 1u][bucket];
+            u32 p = wl ? sh.lbeg[t & 1u][bucket] : 0u; const u32 end = wl ? p + sh.lcnt[t & 1u][bucket] : 0u;
             u32 ne = 0, nb = 0;
             for (;;) {
                 // every lane settles records from their phase-A summaries, LZ_ST_BATCH at a time, until one needs a
@@ -1321,7 +1351,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
                     const int src = (int)__ffsll((long long)mask) - 1;
                     mask &= mask - 1;
                     const u32 sp2 = (u32)__shfl((int)pp2, src), spay = (u32)__shfl((int)ppay, src), sdend = (u32)__shfl((int)dend, src);
-                    const u32 sh_ = part * LZ_NBIN + w * 64u + (u32)src;
+                    const u32 sh_ = part * LZ_NBIN + w * BPW + (u32)src;
                     const s32 diag = (s32)((spay << 16) | sh_);
                     const u32 pos1 = sp2 + (u32)diag;
                     s32 stopl = (s32)sdend + diag;  if (stopl < 0) stopl = 0;                                     // :2612-2616
@@ -1346,7 +1376,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
         }
         __syncthreads();
     }
-    diag_end[h] = dend;
+    if (wl) diag_end[h] = dend;
     for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
     if (lane == 0) {
         if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);
