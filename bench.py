@@ -341,7 +341,7 @@ def run_single(a, torch, lib):
 
     # ---- the lastz CLI bound to this library on the same pair: wall clock + the LAV's fingerprint
     cli = None
-    gpu_bin = os.path.join(ROOT, "oracle", "_ref", "lastz_gpu")
+    gpu_bin = os.path.join(ROOT, "integration", "_build", "lastz_gpu")
     if not a.no_cli and os.path.exists(gpu_bin):
         with tempfile.TemporaryDirectory() as d:
             tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
@@ -349,7 +349,7 @@ def run_single(a, torch, lib):
             c0 = time.time()
             p = subprocess.run([gpu_bin, "t.fa", "q.fa", "--ydrop=9430"], capture_output=True, text=True, cwd=d)
             cw = time.time() - c0
-            cli = {"command": "oracle/_ref/lastz_gpu t.fa q.fa --ydrop=9430 (reference host code + integration/lzgpu_shim.c + liblzgpu.so)",
+            cli = {"command": "integration/_build/lastz_gpu t.fa q.fa --ydrop=9430 (reference host code + integration/lzgpu_shim.c + liblzgpu.so)",
                    "wall_s": round(cw, 3), "rc": p.returncode, "lav_blocks": p.stdout.count("\na {")}
             if p.returncode == 0:
                 fp = lav_fingerprint(p.stdout)

@@ -25,7 +25,11 @@
 #include "seed_search.h"
 #include "gapped_extend.h"
 #include "diag_hash.h"
+#include "capsule.h"
+#include "quantum.h"
 #include "lzgpu.h"
+#include <sys/stat.h>
+#include <errno.h>
 
 /* the reference's own routines, renamed at compile time */
 postable* ref_build_seed_position_table (seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* seed, u32 step);
@@ -38,9 +42,21 @@ u64       ref_seed_hit_search (seq* seq1, postable* pt, seq* seq2, unspos start,
 alignel*  ref_gapped_extend (seq* seq1, u8* rev1, seq* seq2, u8* rev2, int inhibitTrivial, scoreset* scoring,
                              segtable* anchors, tback* tb, int allBounds, score yDrop, int trimToPeak,
                              sthresh scoreThresh, u64 maxPairedBases, int overlyPairedWarn, int overlyPairedKeep);
+/* host-side readers of the table (src/pos_table.h:245-250, src/capsule.h:315, src/quantum.h:118), renamed likewise:
+   the host copy of a table built on the device is filled in only when one of them (or a reference fall-back) is
+   about to read it */
+void      ref_dump_position_table (FILE* f, postable* pt, seed* hitSeed, int showPositions, int showCounts);
+unspos    ref_count_position_table (postable* pt);
+poscount* ref_position_table_count_distribution (postable* pt);
+u32       ref_find_position_table_limit (postable* pt, float keep);
+u64       ref_write_capsule_file (FILE* f, char* filename, seq* seq, u8* revNucs, postable* pt, seed* seed);
+u32       ref_quantum_seed_hit_search (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end,
+                                       const s8 charToBits[], seed* hitSeed, scoreset* scoring, score ballScore,
+                                       hitprocessor processor, void* processorInfo);
 
 /* which host objects the device copy currently mirrors */
 static postable* devTable   = NULL;
+static int       devTableOnHost = false;                   /* devTable->last / ->prev hold the table (lzgpu_table_export ran) */
 static u8*       devTargetV = NULL;
 static unspos    devTargetLen = 0;
 static s8        devCharToBits[256];
@@ -65,7 +81,20 @@ static void note (const char* what, const char* how)
 		}
 	}
 
-static void drop_device_table (void) { devTable = NULL;  devTargetV = NULL;  devTargetLen = 0; }
+static void drop_device_table (void) { devTable = NULL;  devTargetV = NULL;  devTargetLen = 0;  devTableOnHost = false; }
+
+/* The host copy in the reference's layout (last[] / prev[]) costs a device-to-host copy of 64 MiB + 4 bytes per
+ * target base; the search and the gapped stage never read it.  It is made on demand: before any reference routine
+ * that reads a position table runs on the table the device built. */
+static void host_table_needed (postable* pt)
+	{
+	int rc;
+	if ((pt == NULL) || (pt != devTable) || (devTableOnHost)) return;
+	rc = lzgpu_table_export (pt->last, pt->prev);
+	if (rc != 0) suicidef ("lzgpu_table_export: %s", lzgpu_last_error());
+	devTableOnHost = true;
+	note ("table", "copied to the host for a reference routine");
+	}
 
 /* ---- one process per GPU (lastz_amd/multi.py launches them): LZGPU_RANK / LZGPU_WORLD name this process,
  * LZGPU_SHARE_DIR is a directory all ranks see (the table rendezvous), LZGPU_UNIT_PLAN a text file of
@@ -209,17 +238,17 @@ postable* build_seed_position_table
 		{
 		char dir[1024];                                            /* one rendezvous directory per table of the run */
 		snprintf (dir, sizeof(dir), "%s/table%d", mgDir, mgTables++);
-		if (mgRank == 0) { char cmd[1100];  snprintf (cmd, sizeof(cmd), "mkdir -p '%s'", dir);  if (system (cmd) != 0) suicidef ("cannot create %s", dir); }
+		if ((mgRank == 0) && (mkdir (dir, 0700) != 0) && (errno != EEXIST)) suicidef ("cannot create %s: %s", dir, strerror (errno));
 		rc = lzgpu_table_share (mgRank, mgWorld, dir);
 		if (rc != 0) suicidef ("lzgpu_table_share: %s", lzgpu_last_error());
 		note ("table", (mgRank == 0)? "shared with the other ranks" : "received from rank 0");
 		}
 
-	/* host copy in the reference's layout: capsule writer, masking, --tableonly keep working */
+	/* the host object in the reference's layout (callers free it, read its geometry); its arrays are filled by
+	   host_table_needed() only if the capsule writer, masking, --tableonly or a reference fall-back reads them */
 	pt = new_position_table (hitSeed->weight, start, e, step, true, true, false);
-	rc = lzgpu_table_export (pt->last, pt->prev);
-	if (rc != 0) suicidef ("lzgpu_table_export: %s", lzgpu_last_error());
-	devTable = pt;  devTargetV = seq->v;  devTargetLen = seq->len;
+	devTable = pt;  devTableOnHost = false;  devTargetV = seq->v;  devTargetLen = seq->len;
+	if (getenv ("LZGPU_EAGER_EXPORT") != NULL) host_table_needed (pt);
 	memcpy (devCharToBits, upperCharToBits, 256);
 	note ("table", "built on the GPU");
 	return pt;
@@ -230,10 +259,31 @@ void free_position_table (postable* pt)
 
 void mask_seed_position_table
    (postable* pt, seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed)
-	{ if (pt == devTable) drop_device_table ();  ref_mask_seed_position_table (pt, seq, start, end, upperCharToBits, hitSeed); }
+	{ host_table_needed (pt);  if (pt == devTable) drop_device_table ();  ref_mask_seed_position_table (pt, seq, start, end, upperCharToBits, hitSeed); }
 
 void limit_position_table (postable* pt, u32 limit, unspos maxChasm)
-	{ if (pt == devTable) drop_device_table ();  ref_limit_position_table (pt, limit, maxChasm); }
+	{ host_table_needed (pt);  if (pt == devTable) drop_device_table ();  ref_limit_position_table (pt, limit, maxChasm); }
+
+void dump_position_table (FILE* f, postable* pt, seed* hitSeed, int showPositions, int showCounts)
+	{ host_table_needed (pt);  ref_dump_position_table (f, pt, hitSeed, showPositions, showCounts); }
+
+unspos count_position_table (postable* pt)
+	{ host_table_needed (pt);  return ref_count_position_table (pt); }
+
+poscount* position_table_count_distribution (postable* pt)
+	{ host_table_needed (pt);  return ref_position_table_count_distribution (pt); }
+
+u32 find_position_table_limit (postable* pt, float keep)
+	{ host_table_needed (pt);  return ref_find_position_table_limit (pt, keep); }
+
+u64 write_capsule_file (FILE* f, char* filename, seq* seq, u8* revNucs, postable* pt, seed* seed)
+	{ host_table_needed (pt);  return ref_write_capsule_file (f, filename, seq, revNucs, pt, seed); }
+
+u32 quantum_seed_hit_search
+   (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end, const s8 charToBits[], seed* hitSeed,
+	scoreset* scoring, score ballScore, hitprocessor processor, void* processorInfo)
+	{ host_table_needed (pt);
+	  return ref_quantum_seed_hit_search (seq1, pt, seq2, start, end, charToBits, hitSeed, scoring, ballScore, processor, processorInfo); }
 
 /* ---- B2 ---- */
 
@@ -256,7 +306,7 @@ u64 seed_hit_search
 	 || (seq2->fileType == seq_type_qdna) || (hp->seq1 != seq1) || (hp->seq2 != seq2)
 	 || (memcmp (upperCharToBits, devCharToBits, 256) != 0)
 	 || (seed_search_dbgDumpRawHits) || (seed_search_dbgShowHits) || (seed_search_dbgShowCoverage))
-		{ note ("search", "reference path");
+		{ note ("search", "reference path");  host_table_needed (pt);
 		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
 		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
 
@@ -272,7 +322,7 @@ u64 seed_hit_search
 	rc = lzgpu_seed_hit_search (&a, &h, &n);
 	if (rc < 0) suicidef ("lzgpu_seed_hit_search: %s", lzgpu_last_error());
 	if (rc > 0)
-		{ note ("search", "declined, reference path");
+		{ note ("search", "declined, reference path");  host_table_needed (pt);
 		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
 		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
 

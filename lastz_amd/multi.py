@@ -1,46 +1,119 @@
 """One lastz process per GPU (BASELINE.json configs[3] / [4]): launcher and output merger for the reference CLI bound
-to liblzgpu.so (oracle/_ref/lastz_gpu, integration/lzgpu_shim.c).
+to liblzgpu.so (integration/_build/lastz_gpu, integration/lzgpu_shim.c).
 
     python -m lastz_amd.multi --ranks N [--lastz PATH] -- <target> <query> [lastz options] > merged.lav
 
-Every rank runs the SAME command on the SAME files.  The (query sequence, strand) units -- the granularity at
-which the hot path shards exactly (src/seed_search.c:362, src/gapped_extend.c:1051) -- are dealt out by longest
-processing time first (lastz_amd/shard.py) through a plan file; rank 0 builds the position table on its GPU and
-lzgpu_table_share hands it to the other ranks (RCCL broadcast over xGMI; LZGPU_SHARE_TRANSPORT=file when the ranks
-share one device).  A rank produces the stanzas of its own units only; this module puts them back in the
-reference's order: queries in file order, + strand before - strand (src/lastz.c:1592-1691).  LAV only.
+The (query sequence, strand) units -- the granularity at which the hot path shards exactly (src/seed_search.c:362,
+src/gapped_extend.c:1051) -- are dealt out by longest processing time first (lastz_amd/shard.py) through a plan
+file; rank 0 builds the position table on its GPU and lzgpu_table_share hands it to the other ranks (RCCL broadcast
+over xGMI; LZGPU_SHARE_TRANSPORT=file when the ranks share one device).
+
+A rank pays host time only for the query sequences it owns: the launcher indexes the query FASTA once (offsets of
+the records) and gives every rank its own query file in which the records of the other ranks are reduced to
+their header lines.  The reference skips an empty record with a warning (src/lastz.c:1478-1484) after counting it
+(src/sequences.c:2079), so the contig numbers -- which LAV prints -- stay those of the original file, and a rank
+neither parses nor reverse-complements a base it does not own.  (Round 2 ran the whole host loop of every query on
+every rank: about 1 s of host time per 50 Mbp of query, whoever owned it.)  Queries that are not plain FASTA files
+(2bit, hsx, files with actions other than the ones passed through) fall back to "every rank reads everything".
+
+A rank produces the stanzas of its own units only; this module puts them back in the reference's order: queries in
+file order, + strand before - strand (src/lastz.c:1592-1691).  LAV only (checked before anything is launched).
 """
 import argparse
+import mmap
 import os
 import re
 import shutil
 import subprocess
 import sys
 import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 from lastz_amd import shard
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_LASTZ = os.path.join(ROOT, "oracle", "_ref", "lastz_gpu")
+DEFAULT_LASTZ = os.path.join(ROOT, "integration", "_build", "lastz_gpu")
+
+_ACTIONS = re.compile(r"((?:\[[^\]]*\])*)$")
+
+
+def split_spec(spec):
+    """'path[action][action]' -> (path, '[action][action]')"""
+    m = _ACTIONS.search(spec)
+    return spec[:m.start()], m.group(1)
+
+
+def fasta_index(path):
+    """records of a FASTA file in file order: [(header offset, body offset, end offset, bases)] -- one pass over a
+    memory map, no sequence kept.  `bases` counts the non-newline bytes of the body (what the unit plan weighs).
+    A file without a header line is one record."""
+    path = split_spec(path)[0]
+    size = os.path.getsize(path)
+    if size == 0:
+        return []
+    out = []
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+        starts = []
+        if m[0:1] == b">":
+            starts.append(0)
+        k = m.find(b"\n>")
+        while k >= 0:
+            starts.append(k + 1)
+            k = m.find(b"\n>", k + 1)
+        if not starts or starts[0] != 0:
+            first_end = starts[0] if starts else size
+            if m[0:first_end].strip():
+                out.append((0, 0, first_end, _count_bases(m, 0, first_end)))   # leading sequence without a header
+        for i, s in enumerate(starts):
+            e = starts[i + 1] if i + 1 < len(starts) else size
+            nl = m.find(b"\n", s, e)
+            body = e if nl < 0 else nl + 1
+            out.append((s, body, e, _count_bases(m, body, e)))
+    return out
+
+
+def _count_bases(m, a, b):
+    n, step = 0, 1 << 24
+    for lo in range(a, b, step):
+        chunk = m[lo:min(b, lo + step)]
+        n += len(chunk) - chunk.count(b"\n") - chunk.count(b"\r")
+    return n
 
 
 def fasta_lengths(path):
-    """lengths of the sequences of a FASTA file, in file order (one pass, no sequence kept)"""
-    path = re.sub(r"\[.*\]$", "", path)
-    out, n = [], None
-    with open(path, "rb") as f:
-        for line in f:
-            if line.startswith(b">"):
-                if n is not None:
-                    out.append(n)
-                n = 0
-            elif n is not None:
-                n += len(line.rstrip(b"\r\n"))
-            elif line.strip():                       # a FASTA without a header line
-                n = len(line.rstrip(b"\r\n"))
-    if n is not None:
-        out.append(n)
-    return out
+    """lengths of the sequences of a FASTA file, in file order"""
+    return [r[3] for r in fasta_index(path)]
+
+
+def plan_units(lengths, ranks, whole_sequences=None):
+    """(query, strand) units -> ranks.  Whole sequences (both strands on one rank: the rank parses and reverse-
+    complements the sequence once) whenever that costs at most 5 % in the longest rank's load against dealing the
+    strands out separately; else strand by strand.  whole_sequences = True / False forces one or the other."""
+    by_unit = shard.plan_units(lengths, ranks)
+    by_seq = [[(i, s) for (i, _) in p for s in (0, 1)] for p in shard.plan_units(lengths, ranks, strands=1)]
+    load = lambda plan: max((sum(lengths[i] for i, _ in p) for p in plan), default=0)
+    if whole_sequences is None:
+        whole_sequences = load(by_seq) <= 1.05 * load(by_unit)
+    return by_seq if whole_sequences else by_unit
+
+
+def write_rank_query(src, index, owned, dst):
+    """the query file of one rank: every record's header line, the body of the owned records only"""
+    with open(src, "rb") as fi, open(dst, "wb") as fo:
+        for qi, (hoff, boff, eoff, _) in enumerate(index):
+            lo, hi = (hoff, eoff) if qi in owned else (hoff, boff)
+            fi.seek(lo)
+            left, last = hi - lo, b"\n"
+            while left > 0:
+                buf = fi.read(min(left, 1 << 24))
+                if not buf:
+                    break
+                fo.write(buf)
+                left -= len(buf)
+                last = buf[-1:]
+            if last != b"\n":
+                fo.write(b"\n")
 
 
 def split_lav(text):
@@ -69,11 +142,15 @@ def split_lav(text):
     return (head, trailer), units
 
 
-def merge_lav(texts):
-    """outputs of the ranks -> one LAV in the reference's order"""
+def merge_lav(texts, rename=None):
+    """outputs of the ranks -> one LAV in the reference's order.  rename = [(rank's query file, original query file)]:
+    the s-stanza names the query FILE (src/lav.c:111-149); a rank that read its own copy prints that copy's path."""
     head, allu = None, []
-    for t in texts:
+    for r, t in enumerate(texts):
         h, u = split_lav(t)
+        if rename and rename[r][0] != rename[r][1]:
+            u = [(k, _rename_query(x, rename[r][0], rename[r][1])) for k, x in u]
+            h = (h[0].replace(" " + rename[r][0], " " + rename[r][1], 1) if h[0] else h[0], h[1])   # the command line in the d-stanza
         head = head or h
         allu += u
     keys = [k for k, _ in allu]
@@ -82,10 +159,44 @@ def merge_lav(texts):
     return "#:lav\n" + head[0] + "".join("#:lav\n" + u for _, u in allu) + head[1] + "#:eof\n"
 
 
-def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, transport=None, env=None, keep=False):
-    """-> (merged LAV text, [stderr of each rank], plan)"""
-    lengths = fasta_lengths(query)
-    plan = shard.plan_units(lengths, ranks)
+def _rename_query(unit, old, new):
+    lines = unit.split("\n", 3)                          # "s {", target line, query line, rest
+    if len(lines) >= 3 and lines[2].lstrip().startswith('"' + old):
+        lines[2] = lines[2].replace('"' + old, '"' + new, 1)
+    return "\n".join(lines)
+
+
+def check_supported(target, args):
+    """what the merger cannot put back together is refused before any rank starts"""
+    for a in args:
+        if a.startswith("--format=") or a.startswith("--output-format="):
+            fmt = a.split("=", 1)[1]
+            if fmt not in ("lav", "LAV"):
+                raise ValueError("lastz_amd.multi merges LAV output only (got %s); run the formats the launcher does not "
+                                 "know through a single lastz_gpu process" % a)
+        if a.startswith("--output=") or a == "--markend":
+            raise ValueError("lastz_amd.multi collects the ranks' standard output: %s is not supported" % a)
+    tpath, tact = split_spec(target)
+    if "[multi]" not in tact and os.path.exists(tpath):
+        with open(tpath, "rb") as f:
+            magic = f.read(1)
+        if magic == b">" and len(fasta_index(tpath)) > 1 and "[" not in tact:
+            raise ValueError("the target has several sequences: one lastz_amd.multi run handles one target sequence "
+                             "(or a [multi] target); give the sequence as %s[<name>] or use [multi]" % tpath)
+
+
+def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, transport=None, env=None, keep=False, split=True,
+        whole_sequences=None):
+    """-> (merged LAV text, [stderr of each rank], plan).  After the call run.last holds {"rank_seconds": [...],
+    "owned_bases": [...], "split": bool} of this run."""
+    check_supported(target, list(args))
+    qpath, qact = split_spec(query)
+    index = fasta_index(qpath)
+    lengths = [r[3] for r in index]
+    plan = plan_units(lengths, ranks, whole_sequences)
+    with open(qpath, "rb") as f:
+        is_fasta = f.read(1) == b">"
+    split = split and is_fasta and all(a in ("[unmask]", "[nameparse=darkspace]", "[nameparse=full]") for a in re.findall(r"\[[^\]]*\]", qact))
     tmp = tempfile.mkdtemp(prefix="lzgpu_multi_")
     try:
         planf = os.path.join(tmp, "plan.txt")
@@ -93,7 +204,12 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
             for r, units in enumerate(plan):
                 for (qi, strand) in units:
                     f.write("%d %d %d\n" % (qi + 1, strand, r))
-        procs = []
+        qfiles = [qpath] * ranks
+        if split:
+            qfiles = [os.path.join(tmp, "query.rank%d.fa" % r) for r in range(ranks)]
+            with ThreadPoolExecutor(max_workers=min(ranks, 8)) as ex:
+                list(ex.map(lambda r: write_rank_query(qpath, index, {qi for qi, _ in plan[r]}, qfiles[r]), range(ranks)))
+        procs, t0 = [], []
         for r in range(ranks):
             e = dict(os.environ)
             e.update(env or {})
@@ -101,20 +217,27 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
                       "LOCAL_RANK": str(devices[r] if devices else r)})
             if transport:
                 e["LZGPU_SHARE_TRANSPORT"] = transport
-            procs.append(subprocess.Popen([lastz, target, query] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e))
-        outs, errs = [], []
+            t0.append(time.time())
+            procs.append(subprocess.Popen([lastz, target, qfiles[r] + qact] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e))
+        outs, errs, secs = [None] * ranks, [None] * ranks, [0.0] * ranks
+
+        def wait(r):
+            o, e_ = procs[r].communicate()
+            secs[r] = time.time() - t0[r]
+            outs[r], errs[r] = o.decode(), e_.decode()
+        with ThreadPoolExecutor(max_workers=ranks) as ex:
+            list(ex.map(wait, range(ranks)))
         for r, p in enumerate(procs):
-            o, e_ = p.communicate()
             if p.returncode != 0:
-                for q in procs:
-                    if q.poll() is None:
-                        q.kill()
-                raise RuntimeError("rank %d failed (rc %d): %s" % (r, p.returncode, e_.decode()[-2000:]))
-            outs.append(o.decode()); errs.append(e_.decode())
-        return merge_lav(outs), errs, plan
+                raise RuntimeError("rank %d failed (rc %d): %s" % (r, p.returncode, errs[r][-2000:]))
+        run.last = {"rank_seconds": secs, "owned_bases": [sum(lengths[i] for i in {qi for qi, _ in p}) for p in plan], "split": split}
+        return merge_lav(outs, [(qfiles[r], qpath) for r in range(ranks)]), errs, plan
     finally:
         if not keep:
             shutil.rmtree(tmp, ignore_errors=True)
+
+
+run.last = {}
 
 
 def main():
@@ -122,14 +245,19 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--lastz", default=DEFAULT_LASTZ)
     ap.add_argument("--transport", default=None, help="file: ranks share one device (tests)")
+    ap.add_argument("--no-split", action="store_true", help="every rank reads the whole query file (round 2's behaviour)")
     ap.add_argument("rest", nargs=argparse.REMAINDER, help="-- <target> <query> [lastz options]")
     a = ap.parse_args()
     rest = [x for x in a.rest if x != "--"]
     if len(rest) < 2:
         ap.error("need <target> <query>")
-    merged, errs, _ = run(rest[0], rest[1], rest[2:], ranks=a.ranks, lastz=a.lastz, transport=a.transport)
+    try:
+        merged, errs, _ = run(rest[0], rest[1], rest[2:], ranks=a.ranks, lastz=a.lastz, transport=a.transport, split=not a.no_split)
+    except ValueError as e:
+        sys.exit("lastz_amd.multi: %s" % e)
     sys.stdout.write(merged)
     for r, e in enumerate(errs):
+        e = "".join(l for l in e.splitlines(True) if "contains an empty sequence" not in l and not l.startswith(">"))
         if e.strip():
             sys.stderr.write("[rank %d] %s" % (r, e))
 

@@ -1,5 +1,5 @@
 """The drop-in claim, end to end: the REFERENCE's own command lines (src/Makefile:208-217,295-400)
-run through oracle/_ref/lastz_gpu -- the reference's host code with its three hot-path entry
+run through integration/_build/lastz_gpu -- the reference's host code with its three hot-path entry
 points bound to liblzgpu.so by integration/lzgpu_shim.c -- must give the reference's golden LAV
 byte for byte (modulo the first line of the d-stanza, which holds the command line; that is what
 tools/lav_compare.py ignores too), and must agree byte for byte with the pristine binary on
@@ -14,10 +14,10 @@ import helpers as H
 from lavparse import normalize_lav
 
 pytestmark = pytest.mark.gpu
-GPU_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz_gpu")
+GPU_BIN = os.path.join(H.ROOT, "integration", "_build", "lastz_gpu")
 REF_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz")
 needs_bins = pytest.mark.skipif(not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)),
-                                reason="oracle/_ref/lastz_gpu not built (needs /root/reference at build time)")
+                                reason="integration/_build/lastz_gpu not built (needs /root/reference at build time)")
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ import helpers as H
 from lavparse import normalize_lav
 
 pytestmark = pytest.mark.gpu
-GPU_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz_gpu")
+GPU_BIN = os.path.join(H.ROOT, "integration", "_build", "lastz_gpu")
 REF_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz")
 HOXD70 = os.path.join(H.ROOT, "lastz_amd", "data", "HOXD70.q")
 needs_bins = pytest.mark.skipif(not (os.path.exists(GPU_BIN) and os.path.exists(REF_BIN)), reason="oracle/_ref binaries not built")

@@ -2,6 +2,7 @@
 per-rank outputs and merged back, the unit plan, FASTA lengths."""
 import os
 import numpy as np
+import pytest
 
 from lastz_amd import multi, shard, seqio
 import helpers as H
@@ -40,3 +41,40 @@ def test_fasta_lengths_and_plan(tmp_path):
     assert sorted(u for p in plan for u in p) == [(i, s) for i in range(5) for s in (0, 1)]
     loads = [sum(lens[i] for i, _ in p) for p in plan]
     assert abs(loads[0] - loads[1]) <= max(lens)
+
+
+REF_BIN = os.path.join(H.ROOT, "oracle", "_ref", "lastz")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/lastz not built")
+def test_rank_query_files_keep_contig_numbers_and_output(tmp_path):
+    """The launcher's per-rank query files (records of other ranks reduced to their header lines) through the
+    PRISTINE reference binary: whole sequences per rank, so that each process prints exactly its units, and the
+    merged LAV is the single-process LAV byte for byte (contig numbers, file name in the s-stanzas included)."""
+    import subprocess
+    t = os.path.join(H.GOLDEN, "pseudocat.fa"); q = os.path.join(H.GOLDEN, "pseudopig.fa")
+    for args in ([], ["--chain"], ["--nogapped", "--strand=plus"]):
+        single = subprocess.run([REF_BIN, t, q] + args, capture_output=True, text=True, check=True).stdout
+        for ranks in (2, 3):
+            merged, errs, plan = multi.run(t, q, args, ranks=ranks, lastz=REF_BIN, whole_sequences=True)
+            assert merged == single
+            assert multi.run.last["split"] and sum(multi.run.last["owned_bases"]) == sum(multi.fasta_lengths(q))
+            assert all("contains an empty sequence" in e for e in errs)          # what a rank skips, it skips unparsed
+
+
+def test_index_of_a_fasta_and_rank_files(tmp_path):
+    rng = np.random.default_rng(5)
+    seqs = [("s%d extra words" % i, np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]) for i, n in enumerate((300, 61, 1, 777))]
+    seqio.write_fasta(tmp_path / "q.fa", seqs)
+    src = str(tmp_path / "q.fa")
+    idx = multi.fasta_index(src)
+    assert [r[3] for r in idx] == [300, 61, 1, 777]
+    multi.write_rank_query(src, idx, {1, 3}, str(tmp_path / "r.fa"))
+    text = open(tmp_path / "r.fa").read()
+    assert text.count(">") == 4 and [len("".join(blk.split("\n")[1:])) for blk in text.split(">")[1:]] == [0, 61, 0, 777]
+    assert multi.split_spec("a/b.fa[unmask][multi]") == ("a/b.fa", "[unmask][multi]") and multi.split_spec("x.fa") == ("x.fa", "")
+    with pytest.raises(ValueError):
+        multi.check_supported(src, ["--format=maf"])
+    with pytest.raises(ValueError):
+        multi.check_supported(src, [])                                           # several target sequences, no [multi]
+    multi.check_supported(src + "[multi]", ["--format=lav"])

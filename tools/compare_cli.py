@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same box, same inputs, same flags: the pristine reference binary (oracle/_ref/lastz) vs the
-GPU-bound binary (oracle/_ref/lastz_gpu) through the lastz CLI; byte-compares the LAV (modulo the
+GPU-bound binary (integration/_build/lastz_gpu) through the lastz CLI; byte-compares the LAV (modulo the
 d-stanza's command line) and reports both wall clocks.  One-off evidence tool (not a test):
     python tools/compare_cli.py --tlen 10000000 --qlen 10000000 [--nogapped]"""
 import argparse
@@ -35,7 +35,7 @@ def main():
         outs = {}
         for name in (("lastz_gpu",) if a.gpu_only else ("lastz_gpu", "lastz")):
             t0 = time.time()
-            p = subprocess.run([os.path.join(ROOT, "oracle", "_ref", name), "t.fa", "q.fa"] + flags, cwd=d,
+            p = subprocess.run([os.path.join(ROOT, "integration", "_build", name) if name == "lastz_gpu" else os.path.join(ROOT, "oracle", "_ref", name), "t.fa", "q.fa"] + flags, cwd=d,
                                capture_output=True, text=True)
             res[name + "_wall_s"] = round(time.time() - t0, 3)
             if p.returncode != 0:

@@ -10,7 +10,7 @@ seqio.write_fasta("/tmp/mq.fa", [("q1", q[:7_000_000]), ("q2", q[7_000_000:12_00
 PY
 cd /tmp
 ARGS="--chain --inner=2000 --scores=$GRAFT_REPO_ROOT/lastz_amd/data/HOXD70.q --ydrop=9430"
-s=$(date +%s.%N); $GRAFT_REPO_ROOT/oracle/_ref/lastz_gpu mt.fa mq.fa $ARGS > single.lav 2> single.err; e=$(date +%s.%N); python -c "print('single process %.2f s' % ($e - $s))"
+s=$(date +%s.%N); $GRAFT_REPO_ROOT/integration/_build/lastz_gpu mt.fa mq.fa $ARGS > single.lav 2> single.err; e=$(date +%s.%N); python -c "print('single process %.2f s' % ($e - $s))"
 s=$(date +%s.%N); python -m lastz_amd.multi --ranks 2 --transport file -- mt.fa mq.fa $ARGS > multi.lav 2> multi.err; rc=$?; e=$(date +%s.%N); python -c "print('two ranks %.2f s rc=$rc' % ($e - $s))"
 python - <<'PY'
 import sys
