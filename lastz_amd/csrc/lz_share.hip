@@ -22,27 +22,46 @@ typedef int (*fn_bcast)(const void* send, void* recv, size_t count, int dtype, i
 typedef int (*fn_destroy)(void* comm);
 typedef const char* (*fn_errstr)(int);
 
+// Rendezvous files start with the run's nonce (LZGPU_SHARE_NONCE, set by the launcher; 16 bytes, zero-padded): a
+// file left behind by an earlier run in a reused directory is not adopted.  A rank that fails drops `abort` into
+// the directory's parent (the launcher does the same when a rank dies): waiting ranks give up at once instead of
+// sitting out the timeout (LZGPU_SHARE_TIMEOUT_S, default 600).
+struct Nonce { char b[16]; };
+Nonce run_nonce() { Nonce n; memset(&n, 0, sizeof(n)); if (const char* e = getenv("LZGPU_SHARE_NONCE")) strncpy(n.b, e, sizeof(n.b)); return n; }
+int wait_seconds() { const char* e = getenv("LZGPU_SHARE_TIMEOUT_S"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 600; }
 bool write_file_atomic(const std::string& path, const void* p, size_t n)
 {
     const std::string tmp = path + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
-    const bool ok = fwrite(p, 1, n, f) == n;
+    const Nonce nn = run_nonce();
+    const bool ok = fwrite(&nn, 1, sizeof(nn), f) == sizeof(nn) && fwrite(p, 1, n, f) == n;
     fclose(f);
     return ok && rename(tmp.c_str(), path.c_str()) == 0;
 }
 bool read_file_wait(const std::string& path, void* p, size_t n, int timeout_s)
 {
+    const Nonce want = run_nonce();
+    const size_t cut = path.find_last_of('/');
+    const std::string dir = cut == std::string::npos ? std::string(".") : path.substr(0, cut);
+    const std::string abort1 = dir + "/abort", abort2 = dir + "/../abort";
     for (int t = 0; t < timeout_s * 100; t++) {
         FILE* f = fopen(path.c_str(), "rb");
-        if (f) { const bool ok = fread(p, 1, n, f) == n; fclose(f); if (ok) return true; }
+        if (f) {
+            Nonce got;
+            const bool ok = fread(&got, 1, sizeof(got), f) == sizeof(got) && memcmp(&got, &want, sizeof(got)) == 0 && fread(p, 1, n, f) == n;
+            fclose(f);
+            if (ok) return true;
+        }
+        if ((t & 15) == 15 && (access(abort1.c_str(), F_OK) == 0 || access(abort2.c_str(), F_OK) == 0)) return false;
         usleep(10000);
     }
     return false;
 }
+void drop_abort_marker(const std::string& dir) { FILE* f = fopen((dir + "/../abort").c_str(), "wb"); if (f) fclose(f); }
 }
 
-extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
+static int table_share_impl(int rank, int world, const char* dir)
 {
     LzCtx& c = lz_ctx();
     if (world <= 1 && !getenv("LZGPU_SHARE_FORCE")) return 0;   // (LZGPU_SHARE_FORCE: a one-rank run still goes through the transport -- tests)
@@ -52,7 +71,7 @@ extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
     const std::string d(dir);
     const char* tr = getenv("LZGPU_SHARE_TRANSPORT");
     const bool by_file = tr && strcmp(tr, "file") == 0;
-    const int wait_s = 600;
+    const int wait_s = wait_seconds();
     int rc;
 
     // ---- geometry
@@ -109,6 +128,13 @@ extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
     }
     if (rank != 0 && (rc = lzgpu_table_commit())) return rc;
     return 0;
+}
+
+extern "C" int lzgpu_table_share(int rank, int world, const char* dir)
+{
+    const int rc = table_share_impl(rank, world, dir);
+    if (rc != 0 && dir) drop_abort_marker(dir);                 // the other ranks stop waiting for this one
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -209,12 +209,14 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
             qfiles = [os.path.join(tmp, "query.rank%d.fa" % r) for r in range(ranks)]
             with ThreadPoolExecutor(max_workers=min(ranks, 8)) as ex:
                 list(ex.map(lambda r: write_rank_query(qpath, index, {qi for qi, _ in plan[r]}, qfiles[r]), range(ranks)))
+        share = os.path.join(tmp, "share"); os.makedirs(share)       # rendezvous of the table hand-over (lz_share.hip)
+        nonce = "%016x" % int.from_bytes(os.urandom(8), "little")
         procs, t0 = [], []
         for r in range(ranks):
             e = dict(os.environ)
             e.update(env or {})
-            e.update({"LZGPU_RANK": str(r), "LZGPU_WORLD": str(ranks), "LZGPU_SHARE_DIR": tmp, "LZGPU_UNIT_PLAN": planf,
-                      "LOCAL_RANK": str(devices[r] if devices else r)})
+            e.update({"LZGPU_RANK": str(r), "LZGPU_WORLD": str(ranks), "LZGPU_SHARE_DIR": share, "LZGPU_UNIT_PLAN": planf,
+                      "LZGPU_SHARE_NONCE": nonce, "LOCAL_RANK": str(devices[r] if devices else r)})
             if transport:
                 e["LZGPU_SHARE_TRANSPORT"] = transport
             t0.append(time.time())
@@ -225,11 +227,16 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
             o, e_ = procs[r].communicate()
             secs[r] = time.time() - t0[r]
             outs[r], errs[r] = o.decode(), e_.decode()
+            if procs[r].returncode != 0:                        # a rank died: the others must not wait for its table / id
+                open(os.path.join(share, "abort"), "wb").close()
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
         with ThreadPoolExecutor(max_workers=ranks) as ex:
             list(ex.map(wait, range(ranks)))
-        for r, p in enumerate(procs):
-            if p.returncode != 0:
-                raise RuntimeError("rank %d failed (rc %d): %s" % (r, p.returncode, errs[r][-2000:]))
+        bad = [r for r, p in enumerate(procs) if p.returncode != 0 and p.returncode != -9] or [r for r, p in enumerate(procs) if p.returncode != 0]
+        if bad:
+            raise RuntimeError("rank %d failed (rc %d): %s" % (bad[0], procs[bad[0]].returncode, errs[bad[0]][-2000:]))
         run.last = {"rank_seconds": secs, "owned_bases": [sum(lengths[i] for i in {qi for qi, _ in p}) for p in plan], "split": split}
         return merge_lav(outs, [(qfiles[r], qpath) for r in range(ranks)]), errs, plan
     finally:

@@ -57,7 +57,9 @@ def test_two_ranks_merge_to_the_single_process_and_reference_output(pair, name):
     assert "[lzgpu] table: shared with the other ranks" in errs[0] and "[lzgpu] table: received from rank 0" in errs[1]
     for r in (0, 1):
         assert errs[r].count("[lzgpu] search: done on the GPU") == len(plan[r])
-        assert errs[r].count("[lzgpu] search: unit of another rank") == 6 - len(plan[r])
+        loaded = len({qi for qi, _ in plan[r]})                  # a rank reads only the sequences it owns a strand of
+        assert errs[r].count("[lzgpu] search: unit of another rank") == 2 * loaded - len(plan[r])
+        assert errs[r].count("contains an empty sequence") == 3 - loaded
         assert "[lzgpu] gapped: done on the GPU" in errs[r]
     assert "[lzgpu] gapped: done on the GPU" in err1
 
@@ -73,3 +75,34 @@ def test_rccl_transport_with_one_rank(pair):
     assert "[lzgpu] table: shared with the other ranks" in err
     assert os.path.exists(share / "table0" / "nccl_id") and os.path.exists(share / "table0" / "geom")
     assert normalize_lav(out) == normalize_lav(ref)
+
+
+@needs_bins
+def test_a_rank_parses_only_what_it_owns_at_size(tmp_path):
+    """configs[3] at a size where host time shows: a 200 Mbp target, two query sequences of 50 and 25 Mbp, two ranks
+    (one GPU, file transport).  Each rank gets the query file with the other rank's record reduced to its header:
+    its wall time follows the bases it owns, the table is never copied to the host (no reference routine reads it),
+    and the merged LAV is the single-process LAV byte for byte."""
+    import time
+    t, qa = seqio.synth_pair(200_000_000, 50_000_000, seed=301)
+    _, qb = seqio.synth_pair(200_000_000, 25_000_000, seed=302)
+    seqio.write_fasta(tmp_path / "t.fa", [("target", t)])
+    seqio.write_fasta(tmp_path / "q.fa", [("qa", qa), ("qb", qb)])
+    tf, qf = str(tmp_path / "t.fa"), str(tmp_path / "q.fa")
+    env = {"LZGPU_VERBOSE": "1", "LZGPU_VERBOSE_CLOCK": "1"}
+    merged, errs, plan = multi.run(tf, qf, ["--nogapped"], ranks=2, lastz=GPU_BIN, devices=[0, 0], transport="file", env=env)
+    info = dict(multi.run.last)
+    t0 = time.time()
+    single, err1 = _run(GPU_BIN, [tf, qf, "--nogapped"], tmp_path, {"LZGPU_VERBOSE": "1"})
+    single_s = time.time() - t0
+    assert merged == single                                     # byte for byte, d-stanza included
+    assert info["split"] and sorted(info["owned_bases"]) == [25_000_000, 50_000_000]
+    big = info["owned_bases"].index(50_000_000)
+    assert plan[big] == [(0, 0), (0, 1)] and plan[1 - big] == [(1, 0), (1, 1)]
+    for r in (0, 1):
+        assert errs[r].count("[lzgpu] search: done on the GPU") == 2 and "unit of another rank" not in errs[r]
+        assert "copied to the host for a reference routine" not in errs[r]
+        assert errs[r].count("contains an empty sequence") == 1
+    print("single %.1f s; ranks %s s for %s owned bases" % (single_s, ["%.1f" % x for x in info["rank_seconds"]], info["owned_bases"]))
+    # the smaller rank is done well before the larger one (both wait for rank 0's table first)
+    assert info["rank_seconds"][1 - big] < info["rank_seconds"][big]
