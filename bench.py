@@ -187,6 +187,33 @@ def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False, whole_host=True):
     return out
 
 
+def seed_roofline(prof, cnt, K, num_probes, dt):
+    """`roofline` object of the seed stage's dominant kernel from the library's HIP-event timer and work counters.
+    Algorithmic bytes per step, SURVEY.md 8(d): B_seed = W*(1+4V) + 8H + 4E + X, split over the kernels that do each
+    part: the table probes and chain links (count, fill), the bases the X-drop scans touch (phase A = k_scan_hits),
+    the diagEnd read / write per hit / extension (phase B = k_settle)."""
+    W, Hh, E, X = (cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended"))
+    V = num_probes
+    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_scan_hits": X, "k_settle": 4 * Hh + 4 * E}
+    b_seed = W * (1 + 4 * V) + 8 * Hh + 4 * E + X
+    kern_ms = {k: v["ms"] / K for k, v in prof.items()}
+    dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k], default=None)
+    if not dom or not prof[dom]["launches"] or not prof[dom]["ms"]:
+        return None
+    launches = prof[dom]["launches"] / K
+    avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
+    ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
+            "launches_per_step": launches,
+            # whole seed stage against the same roofline, on wall time
+            "stage": {"b_seed_bytes_per_step": b_seed, "wall_ms_per_step": dt / K * 1e3,
+                      "sum_kernel_ms_per_step": sum(kern_ms.values()),
+                      "frac_of_hbm_peak": b_seed / (dt / K) / 1e9 / HBM_PEAK_GBS}}
+
+
 def hsp_rows_sha(hsps_by_strand):
     """sha256 of the rows `lastz --nogapped --format=general-:name2,start1,end1,start2,end2,strand2,score` prints"""
     h = hashlib.sha256()
@@ -360,30 +387,8 @@ def run_single(a, torch, lib):
                     cli["speedup_vs_reference_cli"] = gold["reference_wall_s"]["gapped"] / cw
 
     W, Hh, E, X = (cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended"))
-    # algorithmic bytes per step (both strands), SURVEY.md 8(d): B_seed = W*(1+4V) + 8H + 4E + X, split over the
-    # kernels that do each part: the table probes and chain links (count, fill), the bases the X-drop scans touch
-    # (phase A = k_probe_part, which scans every hit and partitions the records), the diagEnd read / write per hit /
-    # extension (phase B = k_settle, which settles hits from the summaries)
-    V = sd.num_probes
-    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_scan_hits": X, "k_settle": 4 * Hh + 4 * E}
-    b_seed = W * (1 + 4 * V) + 8 * Hh + 4 * E + X
     kern_ms = {k: v["ms"] / K for k, v in prof.items()}
-    dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k], default=None)
-    roof = None
-    if dom:
-        launches = prof[dom]["launches"] / K
-        avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
-        ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
-                "launches_per_step": launches,
-                # whole seed stage against the same roofline, on WALL time (phase B of a chunk overlaps the
-                # next chunk's fill / scan on a second stream, so per-kernel event times add up to more)
-                "stage": {"b_seed_bytes_per_step": b_seed, "wall_ms_per_step": dt / K * 1e3,
-                          "sum_kernel_ms_per_step": sum(kern_ms.values()),
-                          "frac_of_hbm_peak": b_seed / (dt / K) / 1e9 / HBM_PEAK_GBS}}
+    roof = seed_roofline(prof, cnt, K, sd.num_probes, dt)
     value = (a.tlen / 1e9) / (dt / K)
     out = {"metric": "Gbp-of-target aligned/sec (whole job, --nogapped HSP path, both strands)",
            "value": value, "unit": "Gbp/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
@@ -440,13 +445,24 @@ def run_multi(a, torch, lib, world, rank, local, dist):
     dev = torch.device("cuda", local)
     merged = [None]
 
+    phase = {"table_build": 0.0, "table_broadcast": 0.0, "search": 0.0, "gather_merge": 0.0}
+
+    def lap(name, t):
+        torch.cuda.synchronize()
+        now = time.perf_counter(); phase[name] += now - t
+        return now
+
     def step():
+        t = time.perf_counter()
         if rank == 0:
             lib.table_rebuild()
+        t = lap("table_build", t)
         bcast_table(torch, dist, lib, rank, local)
         if rank != 0:
             lib.table_commit()
+        t = lap("table_broadcast", t)
         res = {u: lib.seed_hit_search(masked, slot=slots[u]) for u in mine}
+        t = lap("search", t)
         # HSP lists to rank 0: sizes, then one padded gather; merged in file order, + before -
         flat = np.concatenate([res[u].view(np.uint8) for u in mine]) if mine and sum(len(res[u]) for u in mine) else np.zeros(0, np.uint8)
         sizes = [None] * world
@@ -468,17 +484,32 @@ def run_multi(a, torch, lib, world, rank, local, dist):
                     d[tuple(u)] = arr[o:o + n]; o += n
                 per_rank.append(d)
             merged[0] = shard.merge_units(per_rank)
+        lap("gather_merge", t)
 
     def fence():
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    # A step is the whole job (30 units): seconds, not milliseconds.  The step counts the driver asks for are kept
+    # unless warm-up + timed steps would run past --time-budget-s; then rank 0 decides on fewer (never fewer than
+    # one timed step) from the first warm-up step's duration and every rank follows; the JSON line reports both.
+    steps, warmup = max(a.steps, 1), a.warmup
+    fence(); w0 = time.perf_counter()
+    step()                                              # warm-up step 0 (also the probe for the budget)
+    fence(); first = time.perf_counter() - w0
+    plan_steps = [steps, max(warmup - 1, 0)]
+    if rank == 0 and first * (steps + warmup) > a.time_budget_s:
+        plan_steps = [max(1, min(steps, int(a.time_budget_s / first) - 1)), 0]
+    dist.broadcast_object_list(plan_steps, src=0)
+    steps_run, more_warm = plan_steps
+    for _ in range(more_warm):
         step()
+    for k in phase:
+        phase[k] = 0.0
     lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps_run):
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -486,10 +517,14 @@ def run_multi(a, torch, lib, world, rank, local, dist):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     lib.profile_enable(False)
-    prof = lib.profile()
-    K = max(a.steps, 1)
+    prof, cnt = lib.profile(), lib.counters()
+    K = steps_run
     if rank == 0:
         kern_ms = {k: v["ms"] / K for k, v in prof.items()}
+        cb = None
+        if not a.no_cpu_baseline:                           # the pristine reference on one host core, bounded sample of the same shape
+            qs = seqio.synth_query(target[:a.cpu_sample], min(a.cpu_sample, ulen), seed=3100)
+            cb = cpu_baseline(target, qs, a.qlen, min(a.cpu_sample, tlen, len(qs)), gapped=False, whole_host=False)
         nh = sum(len(v) for _, v in merged[0]) if merged[0] else 0
         assert merged[0] is None or [u for u, _ in merged[0]] == [(i, s) for i in range(nu) for s in (0, 1)]
         out = {"metric": "Gbp-of-target aligned/sec (whole job, --nogapped HSP path, both strands)",
@@ -497,7 +532,7 @@ def run_multi(a, torch, lib, world, rank, local, dist):
                # here the target meets nu * ulen bases of query per step: the same quantity, i.e. the same
                # bp^2 / s rate, is Tlen * (nu * ulen / a.qlen) / t -- so that the per-N values are comparable
                "value": (tlen / 1e9) * (float(nu) * float(ulen) / float(a.qlen)) / (dt / K), "unit": "Gbp/s", "n_gpus": world,
-               "steps": a.steps, "warmup": a.warmup,
+               "steps": steps_run, "warmup": 1 + more_warm, "steps_requested": a.steps, "warmup_requested": a.warmup,
                "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "s32", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[3] shape: synthetic %d bp target vs %d query sequences x %d bp "
@@ -512,7 +547,11 @@ def run_multi(a, torch, lib, world, rank, local, dist):
                "bp2_per_s": float(tlen) * float(nu) * float(ulen) * 2.0 / (dt / K),
                "target_passes_gbp_per_s": float(nu) * (tlen / 1e9) / (dt / K),
                "hsps_merged": int(nh), "units_per_rank": [len(p) for p in plan],
-               "kernel_ms_per_step_rank0": kern_ms, "roofline": None, "cpu_baseline": None}
+               # rank 0's clocks of the parts of a step (the table is built and broadcast once per job = once per step)
+               "phase_ms_per_step_rank0": {k: v / K * 1e3 for k, v in phase.items()},
+               "kernel_ms_per_step_rank0": kern_ms,
+               "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt),      # rank 0's launches of the dominant kernel
+               "cpu_baseline": cb}
         print(json.dumps(out))
 
 
@@ -532,6 +571,7 @@ def main():
     ap.add_argument("--tlen-multi", type=int, default=200_000_000, help="N > 1: target length (configs[3]: 200 Mbp)")
     ap.add_argument("--q-units", type=int, default=15, help="N > 1: query sequences (configs[3]: 15)")
     ap.add_argument("--q-unit-len", type=int, default=200_000_000, help="N > 1: bases per query sequence (configs[3]: 200 Mbp)")
+    ap.add_argument("--time-budget-s", type=float, default=1200.0, help="N > 1: warm-up + timed steps are cut to fit (a step is the whole 3 Gbp job)")
     a = ap.parse_args()
 
     import torch                                   # before liblzgpu.so: one HIP runtime per process
