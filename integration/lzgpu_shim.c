@@ -259,7 +259,14 @@ void free_position_table (postable* pt)
 
 void mask_seed_position_table
    (postable* pt, seq* seq, unspos start, unspos end, const s8 upperCharToBits[], seed* hitSeed)
-	{ host_table_needed (pt);  if (pt == devTable) drop_device_table ();  ref_mask_seed_position_table (pt, seq, start, end, upperCharToBits, hitSeed); }
+	{
+	/* dynamic masking (--masking=<count>, src/masking.c) has just rewritten bases of seq->v IN PLACE and now
+	   removes their seeds from the table: the device's table AND its copy of the target bytes (which the gapped
+	   stage reads, with or without a table) are stale from here on */
+	host_table_needed (pt);
+	if ((pt == devTable) || ((seq != NULL) && (seq->v == devTargetV))) drop_device_table ();
+	ref_mask_seed_position_table (pt, seq, start, end, upperCharToBits, hitSeed);
+	}
 
 void limit_position_table (postable* pt, u32 limit, unspos maxChasm)
 	{ host_table_needed (pt);  if (pt == devTable) drop_device_table ();  ref_limit_position_table (pt, limit, maxChasm); }
