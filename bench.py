@@ -394,7 +394,8 @@ def run_single(a, torch, lib):
            "value": value, "unit": "Gbp/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "s32", "data": "synthetic",
-           "config": {"workload": "BASELINE.json configs[1]: synthetic %d bp target vs %d bp query, 12-of-19 seed + 1 transition, "
+           "config": {"workload": ("BASELINE.json north_star size: " if a.north_star else "BASELINE.json configs[1]: ") +
+                                  "synthetic %d bp target vs %d bp query, 12-of-19 seed + 1 transition, "
                                   "--nogapped, both strands" % (a.tlen, a.qlen),
                       "tlen": a.tlen, "qlen": a.qlen, "scan_mode": lib.last_scan_mode()},
            "bp2_per_s": float(a.tlen) * float(a.qlen) * 2.0 / (dt / K),
@@ -571,8 +572,13 @@ def main():
     ap.add_argument("--tlen-multi", type=int, default=200_000_000, help="N > 1: target length (configs[3]: 200 Mbp)")
     ap.add_argument("--q-units", type=int, default=15, help="N > 1: query sequences (configs[3]: 15)")
     ap.add_argument("--q-unit-len", type=int, default=200_000_000, help="N > 1: bases per query sequence (configs[3]: 200 Mbp)")
+    ap.add_argument("--north-star", action="store_true", help="BASELINE.json north_star size: 200 Mbp x 200 Mbp, seed stage + Y-drop DP on one GPU "
+                                                              "(no CLI leg, 1-core CPU baseline only; the driver's line stays configs[1])")
     ap.add_argument("--time-budget-s", type=float, default=1200.0, help="N > 1: warm-up + timed steps are cut to fit (a step is the whole 3 Gbp job)")
     a = ap.parse_args()
+    if a.north_star:
+        a.tlen = a.qlen = 200_000_000
+        a.no_cli = True; a.no_whole_host = True
 
     import torch                                   # before liblzgpu.so: one HIP runtime per process
     world, rank, local, dist = setup_dist(torch)

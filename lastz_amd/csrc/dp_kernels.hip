@@ -240,6 +240,12 @@ struct HipDpExec : LzDpExecutor {
             if (all[id].status == LZ_DP_OK && all[id].max_row > g_dp_longest[0]) {
                 g_dp_longest[0] = all[id].max_row; g_dp_longest[1] = all[id].cells; g_dp_longest[2] = all[id].t_rows; g_dp_longest[3] = all[id].t_trace;
             }
+        if (const char* dump = getenv("LZGPU_DPDUMP")) {            // profiling aid: one line per DP of the launch
+            if (FILE* f = fopen(dump, "a")) {
+                for (u32 id : ids) fprintf(f, "%u %u %llu %u %u\n", jobs[id].est_rows, all[id].max_row, (unsigned long long)all[id].cells, all[id].status, slot);
+                fclose(f);
+            }
+        }
         if (getenv("LZGPU_DPPROF")) {
             u64 mr = 0, tr = 0, tt = 0, cells = 0, sum_r = 0, sum_t = 0; u32 rows = 0; u64 ph[4] = { 0, 0, 0, 0 }, ld[5] = { 0, 0, 0, 0, 0 };
             for (u32 id : ids) { sum_r += all[id].t_rows; sum_t += all[id].t_trace;
