@@ -198,6 +198,11 @@ typedef struct lz_gapped_args {
        :1152-1189, and is dropped from the output when inhibit_trivial is set (:1483).                  */
     int32_t        strands_differ; /* seq1->revCompFlags != seq2->revCompFlags                    */
     int32_t        inhibit_trivial;/* gapped_extend's inhibitTrivial                              */
+    /* a rectangle of the two sequences as a problem of its own (the tweener's in-between windows,
+       src/tweener.c:769-829: extract_subsequence + gapped_extend on the pieces): the stage sees
+       target[t_off, t_off + t_len) x query[q_off, q_off + q_len) as its whole sequences -- anchors, sep1 / sep2
+       and the alignments returned are relative to the rectangle.  t_len == 0 / q_len == 0: the whole sequence. */
+    uint32_t       t_off, t_len, q_off, q_len;
 } lz_gapped_args;
 
 typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */
@@ -216,6 +221,15 @@ typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46   
 int lzgpu_target_upload(const uint8_t* t, uint32_t tlen);
 int lzgpu_gapped_extend(const lz_gapped_args* args, lz_align** out, uint64_t* n_out,
                         uint32_t** ops, uint64_t* n_ops);
+/* n independent problems against the same target in one go: the two strands of a query (src/lastz.c:3401-3419 runs
+ * them one after the other), several query sequences, the in-between windows of src/tweener.c.  Every problem keeps
+ * the reference's anchor order and bounds of its own (the results are those of n calls of lzgpu_gapped_extend), but
+ * the one-sided DPs of all of them share the launches, so that the launch of one problem does not sit out the
+ * longest DP of another.  All problems must use the same scoring (sub, gap penalties, ydrop, traceback_bytes);
+ * out / n_out / ops / n_ops are arrays of n, each element freed with lzgpu_free.  The return code is that of the
+ * first problem that did not return 0 (then every out[k] is NULL). */
+int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n, lz_align** out, uint64_t* n_out,
+                              uint32_t** ops, uint64_t* n_ops);
 
 /* ---- instrumentation (bench.py, tests) ---------------------------------------------------- */
 typedef struct lz_counters {       /* same events as the reference's collect_stats build          */

@@ -10,6 +10,10 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
 #include "lz_gapped_host.hpp"
@@ -119,7 +123,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 };
 
 __global__ void __launch_bounds__(LZ_DP_LANES)
-k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
+k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
         const s32* __restrict__ tab_g, LzDpResult* __restrict__ res)
 {
     __shared__ LzDpShared sh;
@@ -130,12 +134,14 @@ k_ydrop(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u3
     GpuPhases x;
     x.lead_wave = (int)((blockIdx.x + (blockIdx.x >> 8)) & (LZ_DP_WAVES - 1));
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
-    lz_dp_run(x, sh, S, P, J, tab, &res[j]);
+    const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its snapshot, its query)
+    P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
+    lz_dp_run(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
 __global__ void __launch_bounds__(LZ_DP_LANES)
-k_ydrop_wide(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
+k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
              const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u8* __restrict__ rings)
 {
     __shared__ LzDpSharedWide sh;
@@ -147,7 +153,9 @@ k_ydrop_wide(LzDpSnapshot S, LzDpParams P, const LzDpJob* __restrict__ jobs, con
     GpuPhases x;
     x.lead_wave = (int)(blockIdx.x & (LZ_DP_WAVES - 1));
     const LzDpJob J = jobs[j];
-    lz_dp_run(x, sh, S, P, J, tab, &res[j]);
+    const LzDpProblem pb = problems[J.problem];
+    P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
+    lz_dp_run(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -163,12 +171,12 @@ k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ re
 }
 
 struct DpBufs {
-    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings, sel_jobs, sel_res;
+    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings, sel_jobs, sel_res, problems;
 };
 static DpBufs g_dp;
 void lz_dp_release_statics()
 {
-    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings, &g_dp.sel_jobs, &g_dp.sel_res };
+    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings, &g_dp.sel_jobs, &g_dp.sel_res, &g_dp.problems };
     for (DevBuf* x : b) x->release();
 }
 
@@ -188,28 +196,41 @@ struct HipDpExec : LzDpExecutor {
     explicit HipDpExec(LzCtx& ctx) : c(ctx) {}
 
     u64 wide_runs = 0;
-    int launch(const LzDpSnapshot& S, std::vector<LzDpJob>& jobs, const std::vector<u32>& ids, u32 slot,
-               std::vector<LzDpResult>& res, bool wide = false)
+    const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
+    // Traceback slots.  A retry gives every DP the same (larger) slot; the first try sizes each DP's slot from the
+    // host's guess of the rows it will sweep (est_rows, lz_gapped_host.cpp: the deferred anchors around the DP's
+    // anchor): on the bench pair rows = 1.2 x est_rows (median; 2.2 x at the 90th percentile) and a row has ~430
+    // cells, so 1000 bytes per estimated row with a floor of 2 MiB held every one of 4602 DPs while the arena shrank
+    // from 27.5 to 14.4 GiB per launch (uniform 8 MiB slots) -- memory a fresh process pays ~25 ms per GiB for.
+    int launch(std::vector<LzDpJob>& jobs, const std::vector<u32>& ids, u32 slot,
+               std::vector<LzDpResult>& res, bool wide = false, bool by_estimate = false)
     {
         // slots: tb = slot bytes, rows = slot/16 entries, ops = slot/32 entries (all per DP)
         const u64 n = ids.size();
-        const u32 row_cap = slot / 16 + 64, ops_cap = slot / 32 + 64;
         int rc;
-        // sized for a multiple of 512 DPs: the two strands of a pair launch slightly different numbers of DPs, and a
-        // buffer that grows is freed and allocated again -- 18 GiB of fresh device memory cost the second strand of
-        // the 50 Mbp CLI run a second (tools/cli_prof.sh)
-        const u64 na = (n + 511) / 512 * 512;
-        if ((rc = g_dp.tb.ensure((size_t)na * slot))) return rc;
-        if ((rc = g_dp.rows.ensure((size_t)na * row_cap * 4))) return rc;
-        if ((rc = g_dp.ops.ensure((size_t)na * ops_cap * 4))) return rc;
-        if ((rc = g_dp.act.ensure((size_t)na * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
+        u64 tb_total = 0, row_total = 0, ops_total = 0;
         for (u64 k = 0; k < n; k++) {
             LzDpJob& J = jobs[ids[k]];
-            J.tb_off = k * (u64)slot; J.tb_cap = slot;
-            J.row_off = k * (u64)row_cap; J.row_cap = row_cap;
-            J.ops_off = k * (u64)ops_cap; J.ops_cap = ops_cap;
+            u64 sl = slot;
+            if (by_estimate) {
+                sl = std::max<u64>((u64)J.est_rows * 1000u, 2u << 20);
+                sl = std::min<u64>((sl + 65535u) & ~65535ull, slot);
+            }
+            const u32 row_cap = (u32)(sl / 16 + 64), ops_cap = (u32)(sl / 32 + 64);
+            J.tb_off = tb_total; J.tb_cap = (u32)sl;        tb_total += sl;
+            J.row_off = row_total; J.row_cap = row_cap;     row_total += row_cap;
+            J.ops_off = ops_total; J.ops_cap = ops_cap;     ops_total += ops_cap;
             J.act_off = k * (u64)(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
         }
+        // a quarter of head room: the launches of a run (two strands, the rounds of a strand) differ a little, and a
+        // buffer that grows is freed and allocated again -- 18 GiB of fresh device memory cost the second strand of
+        // the 50 Mbp CLI run a second (tools/cli_prof.sh)
+        auto room = [](u64 x) { return (size_t)(x + x / 4 + (1u << 20)); };
+        if (tb_total > g_dp.tb.cap && (rc = g_dp.tb.ensure(room(tb_total)))) return rc;
+        if (row_total * 4 > g_dp.rows.cap && (rc = g_dp.rows.ensure(room(row_total * 4)))) return rc;
+        if (ops_total * 4 > g_dp.ops.cap && (rc = g_dp.ops.ensure(room(ops_total * 4)))) return rc;
+        const u64 na = (n + 511) / 512 * 512;
+        if ((rc = g_dp.act.ensure((size_t)na * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
         if ((rc = g_dp.jobs.ensure(jobs.size() * sizeof(LzDpJob)))) return rc;
         if ((rc = g_dp.ids.ensure(n * 4))) return rc;
         if ((rc = g_dp.res.ensure(jobs.size() * sizeof(LzDpResult)))) return rc;
@@ -222,11 +243,11 @@ struct HipDpExec : LzDpExecutor {
             wide_runs += n;
             c.timer.begin("k_ydrop_wide", c.stream);
             hipLaunchKernelGGL(k_ydrop_wide, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
-                               S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
+                               problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.timer.begin("k_ydrop", c.stream);
             hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
-                               S, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
+                               problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
         }
         c.timer.end(c.stream);
         LZ_HIP(hipGetLastError());
@@ -300,22 +321,46 @@ struct HipDpExec : LzDpExecutor {
     int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
             std::vector<std::vector<u32>>& ops) override
     {
+        std::vector<LzDpBatchItem> items(1);
+        items[0].snap = &snap; items[0].jobs = &jobs; items[0].res = &res; items[0].ops = &ops; items[0].qdp = P.qdp; items[0].qlen = P.qlen;
+        items[0].tdp = P.tdp; items[0].tlen = P.tlen;
+        return run_multi(items);
+    }
+
+    // The DPs of several independent problems in one launch (each item: a problem's snapshot, its jobs, its query).
+    int run_multi(std::vector<LzDpBatchItem>& items)
+    {
         int rc;
-        // ---- snapshot of the bounding alignments
-        const size_t na = snap.aligns.size(), ns = snap.segs.size();
+        // ---- the snapshots, back to back; a problem's indices stay relative to its own arrays
+        size_t na = 0, ns = 0, nj = 0;
+        for (auto& it : items) { na += it.snap->aligns.size(); ns += it.snap->segs.size(); nj += it.jobs->size(); }
         if ((rc = g_dp.aligns.ensure((na ? na : 1) * sizeof(LzDpAlign)))) return rc;
         if ((rc = g_dp.segs.ensure((ns ? ns : 1) * sizeof(LzDpSeg)))) return rc;
         if ((rc = g_dp.obi.ensure((na ? na : 1) * 4))) return rc;
         if ((rc = g_dp.oed.ensure((na ? na : 1) * 4))) return rc;
-        if (na) {
-            LZ_HIP(hipMemcpyAsync(g_dp.aligns.p, snap.aligns.data(), na * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.stream));
-            LZ_HIP(hipMemcpyAsync(g_dp.obi.p, snap.obi.data(), na * 4, hipMemcpyHostToDevice, c.stream));
-            LZ_HIP(hipMemcpyAsync(g_dp.oed.p, snap.oed.data(), na * 4, hipMemcpyHostToDevice, c.stream));
+        if ((rc = g_dp.problems.ensure(items.size() * sizeof(LzDpProblem)))) return rc;
+        std::vector<LzDpProblem> pb(items.size());
+        std::vector<LzDpJob> jobs; jobs.reserve(nj);
+        size_t oa = 0, os = 0;
+        for (size_t p = 0; p < items.size(); p++) {
+            const LzHostSnapshot& snap = *items[p].snap;
+            const size_t a = snap.aligns.size(), g = snap.segs.size();
+            if (a) {
+                LZ_HIP(hipMemcpyAsync(g_dp.aligns.as<LzDpAlign>() + oa, snap.aligns.data(), a * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.stream));
+                LZ_HIP(hipMemcpyAsync(g_dp.obi.as<s32>() + oa, snap.obi.data(), a * 4, hipMemcpyHostToDevice, c.stream));
+                LZ_HIP(hipMemcpyAsync(g_dp.oed.as<s32>() + oa, snap.oed.data(), a * 4, hipMemcpyHostToDevice, c.stream));
+            }
+            if (g) LZ_HIP(hipMemcpyAsync(g_dp.segs.as<LzDpSeg>() + os, snap.segs.data(), g * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.stream));
+            pb[p].S.aligns = g_dp.aligns.as<LzDpAlign>() + oa; pb[p].S.segs = g_dp.segs.as<LzDpSeg>() + os;
+            pb[p].S.obi = g_dp.obi.as<s32>() + oa; pb[p].S.oed = g_dp.oed.as<s32>() + oa; pb[p].S.n_aligns = (s32)a;
+            pb[p].qdp = items[p].qdp; pb[p].qlen = items[p].qlen; pb[p].tdp = items[p].tdp; pb[p].tlen = items[p].tlen;
+            oa += a; os += g;
+            for (LzDpJob J : *items[p].jobs) { J.problem = (u32)p; jobs.push_back(J); }
         }
-        if (ns) LZ_HIP(hipMemcpyAsync(g_dp.segs.p, snap.segs.data(), ns * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.stream));
-        LzDpSnapshot S;
-        S.aligns = g_dp.aligns.as<LzDpAlign>(); S.segs = g_dp.segs.as<LzDpSeg>();
-        S.obi = g_dp.obi.as<s32>(); S.oed = g_dp.oed.as<s32>(); S.n_aligns = (s32)na;
+        LZ_HIP(hipMemcpyAsync(g_dp.problems.p, pb.data(), pb.size() * sizeof(LzDpProblem), hipMemcpyHostToDevice, c.stream));
+        problems_dev = g_dp.problems.as<LzDpProblem>();
+        std::vector<LzDpResult> res(jobs.size());
+        std::vector<std::vector<u32>> ops(jobs.size());
 
         // ---- first try: every job in a small slot; then the (rare) overflows in growing slots
         std::vector<u32> ids(jobs.size()), wide_ids;
@@ -324,7 +369,9 @@ struct HipDpExec : LzDpExecutor {
         // first (est_rows, lz_gapped_host.cpp), so that the launch does not end on a long DP that started late
         if (!getenv("LZGPU_DP_NO_ORDER"))
             std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return jobs[a].est_rows > jobs[b].est_rows; });
+        static const bool uniform_slots = getenv("LZGPU_DP_UNIFORM_SLOTS") != nullptr;     // A/B aid: round 2's arena
         u32 slot = slot_tb;
+        bool first_try = !uniform_slots;
         while (!ids.empty() || !wide_ids.empty()) {
             // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch
             const u64 per = (u64)slot + (u64)(slot / 16 + 64) * 4 + (u64)(slot / 32 + 64) * 4;
@@ -337,7 +384,7 @@ struct HipDpExec : LzDpExecutor {
                 const u64 cap = wide ? std::min<u64>(max_jobs, 2048) : max_jobs;      // (2048 rings = 1.8 GiB)
                 for (size_t base = 0; base < todo.size(); base += cap) {
                     std::vector<u32> part(todo.begin() + base, todo.begin() + std::min<size_t>(todo.size(), base + cap));
-                    if ((rc = launch(S, jobs, part, slot, res, wide))) return rc;
+                    if ((rc = launch(jobs, part, slot, res, wide, first_try))) return rc;
                     std::vector<u32> good;
                     for (u32 id : part) {
                         const u32 stt = res[id].status;
@@ -350,9 +397,19 @@ struct HipDpExec : LzDpExecutor {
                 }
             }
             const u64 max_slot = std::max<u64>(P.tb_len, 1u << 20) * 2;
-            if ((!retry.empty() || !retry_wide.empty()) && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
+            if ((!retry.empty() || !retry_wide.empty()) && !first_try && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
             ids.swap(retry); wide_ids.swap(retry_wide);
-            slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
+            if (first_try) first_try = false;                      // (what overflowed its estimated slot: the uniform slot next)
+            else slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
+        }
+        // ---- results back to their problems
+        size_t o = 0;
+        for (auto& it : items) {
+            const size_t n = it.jobs->size();
+            it.res->assign(res.begin() + o, res.begin() + o + n);
+            it.ops->resize(n);
+            for (size_t k = 0; k < n; k++) { (*it.ops)[k].swap(ops[o + k]); (*it.jobs)[k] = jobs[o + k]; (*it.jobs)[k].problem = 0; }
+            o += n;
         }
         return 0;
     }
@@ -366,76 +423,167 @@ extern "C" int lzgpu_set_dp_window(uint32_t n) { if (n < 1) return LZGPU_ERR_ARG
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len);     // lzgpu_api.hip
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256]);
 
-extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops)
-{
-    LzCtx& c = lz_ctx();
-    if (!a || !out || !n_out || !ops || !n_ops || !a->sub) return lz_fail(LZGPU_ERR_ARG, "null argument");
-    *out = nullptr; *n_out = 0; *ops = nullptr; *n_ops = 0;
-    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
-    if (!c.target.have_raw || c.target.host.size() != c.target.len || c.target.len != c.geom.tlen)
-        return lz_fail(LZGPU_ERR_STATE, "no target on the device (lzgpu_table_prepare / lzgpu_target_upload)");
+// Several problems' DPs in the same launches without touching the per-problem host logic: every problem runs
+// lzh_gapped_extend on a thread of its own against a client executor; a client's run() hands the round's jobs to the
+// rendezvous and sleeps; when every problem that is still going has handed in its jobs, the last one to arrive
+// launches them all (HipDpExec::run_multi) and wakes the others.  A problem that finishes leaves the count.
+namespace {
+struct DpRendezvous {
+    HipDpExec& ex; std::mutex m; std::condition_variable cv; int active; u64 gen = 0; int rc = 0;
+    std::vector<LzDpBatchItem> waiting;
+    DpRendezvous(HipDpExec& e, int n) : ex(e), active(n) {}
+    void flush_locked() { rc = ex.run_multi(waiting); waiting.clear(); gen++; cv.notify_all(); }
+    int submit(const LzDpBatchItem& it)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        waiting.push_back(it);
+        if ((int)waiting.size() >= active) { flush_locked(); return rc; }
+        const u64 g = gen;
+        cv.wait(lk, [&] { return gen != g; });
+        return rc;
+    }
+    void leave()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        active--;
+        if (active > 0 && !waiting.empty() && (int)waiting.size() >= active) flush_locked();
+    }
+};
+struct DpClient : LzDpExecutor {
+    DpRendezvous& R; const u8* qdp; u32 qlen; const u8* tdp = nullptr; u32 tlen = 0;
+    DpClient(DpRendezvous& r, const u8* q, u32 n) : R(r), qdp(q), qlen(n) {}
+    int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res, std::vector<std::vector<u32>>& ops) override
+    {
+        LzDpBatchItem it; it.snap = &snap; it.jobs = &jobs; it.res = &res; it.ops = &ops; it.qdp = qdp; it.qlen = qlen; it.tdp = tdp; it.tlen = tlen;
+        return R.submit(it);
+    }
+};
 
-    // ---- query
-    SeqSlot* qs; int rc;
+// what one problem needs besides its arguments: the query on the device (slot), DP codes, the host-side parameters
+struct GappedProblem { SeqSlot* qs = nullptr; LzGappedParams G; const u8* tdp = nullptr; const u8* qdp = nullptr; u32 tlen = 0, qlen = 0; };
+
+// query slot + window + DP class codes of one problem; `temp_slot` names the slot a host pointer is uploaded to
+int gapped_prepare(LzCtx& c, const lz_gapped_args* a, int temp_slot, const u8 rowc[256], const u8 colc[256], bool encode_target,
+                   std::map<SeqSlot*, bool>& encoded, GappedProblem& gp)
+{
+    int rc;
+    if (!a->sub || (!a->anchors && a->n_anchors)) return lz_fail(LZGPU_ERR_ARG, "null argument");
     if (a->query) {
         if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
-        qs = &c.queries[-1];
-        if ((rc = lz_slot_upload_public(c, *qs, a->query, a->qlen))) return rc;
+        gp.qs = &c.queries[temp_slot];
+        if ((rc = lz_slot_upload_public(c, *gp.qs, a->query, a->qlen))) return rc;
     } else {
         auto it = c.queries.find(a->query_slot);
         if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
-        qs = &it->second;
+        gp.qs = &it->second;
     }
+    SeqSlot* qs = gp.qs;
     const u8* qhost = a->query ? a->query : qs->host.data();
-    const u32 qlen = qs->len, tlen = c.geom.tlen;
-
+    const u32 qfull = qs->len, tfull = c.geom.tlen;
+    if ((u64)a->t_off + a->t_len > tfull || (u64)a->q_off + a->q_len > qfull) return lz_fail(LZGPU_ERR_ARG, "window outside the sequences");
+    gp.tlen = a->t_len ? a->t_len : tfull - a->t_off; gp.qlen = a->q_len ? a->q_len : qfull - a->q_off;
     // ---- DP class codes (UNmasked scoring, src/lastz.c:3421)
-    u8 rowc[256], colc[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
-    if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
-    if ((rc = c.target.dp.ensure((size_t)tlen + 2 * LZ_SEQ_PAD + 16))) return rc;
-    if ((rc = qs->dp.ensure((size_t)qlen + 2 * LZ_SEQ_PAD + 16))) return rc;
-    LZ_HIP(hipMemsetAsync(c.target.dp.p, 0, (size_t)tlen + 2 * LZ_SEQ_PAD + 16, c.stream));
-    LZ_HIP(hipMemsetAsync(qs->dp.p, 0, (size_t)qlen + 2 * LZ_SEQ_PAD + 16, c.stream));
-    if ((rc = lz_encode_with(c, c.target.raw_base(), c.target.dp.as<u8>() + LZ_SEQ_PAD, tlen, rowc))) return rc;
-    if ((rc = lz_encode_with(c, qs->raw_base(), qs->dp.as<u8>() + LZ_SEQ_PAD, qlen, colc))) return rc;
-    if ((rc = g_dp.tab.ensure(sizeof(tab)))) return rc;
-    LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
-
-    HipDpExec ex(c);
-    ex.P.tdp = c.target.dp.as<u8>() + LZ_SEQ_PAD; ex.P.tlen = tlen;
-    ex.P.qdp = qs->dp.as<u8>() + LZ_SEQ_PAD;      ex.P.qlen = qlen;
-    ex.P.gap_e = a->gap_extend; ex.P.gap_oe = a->gap_open + a->gap_extend; ex.P.ydrop = a->ydrop;
-    if (a->gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
-    ex.P.ydrop_tail = a->ydrop / a->gap_extend + 6;                      // :3484-3492
-    ex.P.tb_len = a->traceback_bytes ? a->traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
-    ex.slot_tb = g_dp_slot_tb;
-
-    LzGappedParams G;
-    G.t = c.target.host.data(); G.tlen = tlen; G.q = qhost; G.qlen = qlen; G.sub = a->sub;
+    if (encode_target) {
+        if ((rc = c.target.dp.ensure((size_t)tfull + 2 * LZ_SEQ_PAD + 16))) return rc;
+        LZ_HIP(hipMemsetAsync(c.target.dp.p, 0, (size_t)tfull + 2 * LZ_SEQ_PAD + 16, c.stream));
+        if ((rc = lz_encode_with(c, c.target.raw_base(), c.target.dp.as<u8>() + LZ_SEQ_PAD, tfull, rowc))) return rc;
+    }
+    if (!encoded.count(qs)) {
+        if ((rc = qs->dp.ensure((size_t)qfull + 2 * LZ_SEQ_PAD + 16))) return rc;
+        LZ_HIP(hipMemsetAsync(qs->dp.p, 0, (size_t)qfull + 2 * LZ_SEQ_PAD + 16, c.stream));
+        if ((rc = lz_encode_with(c, qs->raw_base(), qs->dp.as<u8>() + LZ_SEQ_PAD, qfull, colc))) return rc;
+        encoded[qs] = true;
+    }
+    gp.tdp = c.target.dp.as<u8>() + LZ_SEQ_PAD + a->t_off; gp.qdp = qs->dp.as<u8>() + LZ_SEQ_PAD + a->q_off;
+    LzGappedParams& G = gp.G;
+    G.t = c.target.host.data() + a->t_off; G.tlen = gp.tlen; G.q = qhost + a->q_off; G.qlen = gp.qlen; G.sub = a->sub;
     G.gap_open = a->gap_open; G.gap_extend = a->gap_extend; G.ydrop = a->ydrop; G.score_thresh = a->score_thresh;
     G.window = g_dp_window;
     G.sep1 = a->sep1; G.n_sep1 = a->sep1 ? a->n_sep1 : 0; G.sep2 = a->sep2; G.n_sep2 = a->sep2 ? a->n_sep2 : 0;
     G.strands_differ = a->strands_differ != 0; G.inhibit_trivial = a->inhibit_trivial != 0;
     if ((a->sep1 && a->n_sep1 < 2) || (a->sep2 && a->n_sep2 < 2)) return lz_fail(LZGPU_ERR_ARG, "a partitioned sequence needs at least two separators");
     if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
-    static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
-    const auto tq0 = std::chrono::steady_clock::now();
-    if (a->reduce) lzh_reduce_to_points(G.t, G.q, G.sub, a->anchors, a->n_anchors);
-    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: reduce_to_points of %u anchors %.2f ms\n", a->n_anchors,
-                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
-    std::vector<lz_align> al; std::vector<u32> op; LzGappedStats st;
-    rc = lzh_gapped_extend(G, ex, a->anchors, a->n_anchors, al, op, st);
-    c.counters.anchors_extended += st.anchors_extended;
-    c.counters.dp_cells += st.dp_cells;                 // cells of the DPs the reference would have run
-    c.counters.gapped_extensions += st.dp_runs;         // DPs actually launched (speculation included)
-    c.counters.truncated_extensions += st.truncated;
-    if (rc) return rc < 0 ? lz_fail(rc, "gapped_extend failed") : rc;
+    return 0;
+}
+int gapped_result(std::vector<lz_align>& al, std::vector<u32>& op, lz_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops)
+{
     *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
     *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);
-    if (!*out || !*ops) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
+    if (!*out || !*ops) { free(*out); free(*ops); *out = nullptr; *ops = nullptr; return lz_fail(LZGPU_ERR_OOM, "host malloc failed"); }
     if (!al.empty()) memcpy(*out, al.data(), al.size() * sizeof(lz_align));
     if (!op.empty()) memcpy(*ops, op.data(), op.size() * 4);
     *n_out = al.size(); *n_ops = op.size();
     return 0;
+}
+}
+
+extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n, lz_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops)
+{
+    LzCtx& c = lz_ctx();
+    if (!args || !out || !n_out || !ops || !n_ops || n == 0) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    for (u32 k = 0; k < n; k++) { out[k] = nullptr; n_out[k] = 0; ops[k] = nullptr; n_ops[k] = 0; }
+    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    if (!c.target.have_raw || c.target.host.size() != c.target.len || c.target.len != c.geom.tlen)
+        return lz_fail(LZGPU_ERR_STATE, "no target on the device (lzgpu_table_prepare / lzgpu_target_upload)");
+    const lz_gapped_args& a0 = args[0];
+    if (!a0.sub) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    for (u32 k = 1; k < n; k++) {
+        const lz_gapped_args& a = args[k];
+        if (!a.sub || a.gap_open != a0.gap_open || a.gap_extend != a0.gap_extend || a.ydrop != a0.ydrop || a.traceback_bytes != a0.traceback_bytes
+            || (a.sub != a0.sub && memcmp(a.sub, a0.sub, 65536 * sizeof(int32_t)) != 0))
+            return lz_fail(LZGPU_ERR_ARG, "lzgpu_gapped_extend_batch: the problems of a batch must share the scoring");
+    }
+    if (a0.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
+    int rc;
+    u8 rowc[256], colc[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
+    if ((rc = lzh_score_classes(a0.sub, rowc, colc, tab))) return rc;
+    std::vector<GappedProblem> gp(n);
+    std::map<SeqSlot*, bool> encoded;                          // (problems may share a query slot -- the windows of a strand: encoded once)
+    for (u32 k = 0; k < n; k++)
+        if ((rc = gapped_prepare(c, &args[k], -1 - (int)k, rowc, colc, k == 0, encoded, gp[k]))) return rc;
+    if ((rc = g_dp.tab.ensure(sizeof(tab)))) return rc;
+    LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+
+    HipDpExec ex(c);
+    ex.P.tdp = gp[0].tdp; ex.P.tlen = gp[0].tlen; ex.P.qdp = gp[0].qdp; ex.P.qlen = gp[0].qlen;
+    ex.P.gap_e = a0.gap_extend; ex.P.gap_oe = a0.gap_open + a0.gap_extend; ex.P.ydrop = a0.ydrop;
+    ex.P.ydrop_tail = a0.ydrop / a0.gap_extend + 6;                      // :3484-3492
+    ex.P.tb_len = a0.traceback_bytes ? a0.traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
+    ex.slot_tb = g_dp_slot_tb;
+
+    DpRendezvous R(ex, (int)n);
+    std::vector<std::vector<lz_align>> al(n); std::vector<std::vector<u32>> op(n); std::vector<LzGappedStats> st(n); std::vector<int> rcs(n, 0);
+    const int dev = c.device;
+    auto work = [&](u32 k) {
+        (void)hipSetDevice(dev);
+        DpClient cl(R, gp[k].qdp, gp[k].qlen);
+        cl.tdp = gp[k].tdp; cl.tlen = gp[k].tlen;
+        if (args[k].reduce) lzh_reduce_to_points(gp[k].G.t, gp[k].G.q, gp[k].G.sub, args[k].anchors, args[k].n_anchors);
+        rcs[k] = lzh_gapped_extend(gp[k].G, cl, args[k].anchors, args[k].n_anchors, al[k], op[k], st[k]);
+        R.leave();
+    };
+    {
+        std::vector<std::thread> th;
+        for (u32 k = 1; k < n; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    for (u32 k = 0; k < n; k++) {
+        c.counters.anchors_extended += st[k].anchors_extended; c.counters.dp_cells += st[k].dp_cells;
+        c.counters.gapped_extensions += st[k].dp_runs; c.counters.truncated_extensions += st[k].truncated;
+    }
+    for (u32 k = 0; k < n; k++) if (rcs[k]) return rcs[k] < 0 ? lz_fail(rcs[k], "gapped_extend failed (problem %u of the batch)", k) : rcs[k];
+    for (u32 k = 0; k < n; k++)
+        if ((rc = gapped_result(al[k], op[k], &out[k], &n_out[k], &ops[k], &n_ops[k]))) {
+            for (u32 j = 0; j <= k; j++) { free(out[j]); free(ops[j]); out[j] = nullptr; ops[j] = nullptr; n_out[j] = 0; n_ops[j] = 0; }
+            return rc;
+        }
+    return 0;
+}
+
+extern "C" int lzgpu_gapped_extend(const lz_gapped_args* a, lz_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops)
+{
+    if (!a || !out || !n_out || !ops || !n_ops) return lz_fail(LZGPU_ERR_ARG, "null argument");
+    return lzgpu_gapped_extend_batch(a, 1, out, n_out, ops, n_ops);     // a batch of one problem
 }

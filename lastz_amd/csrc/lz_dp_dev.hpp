@@ -74,7 +74,13 @@ struct LzDpJob {
     u64 ops_off; u32 ops_cap;           // edit ops slot (u32 each, traceback order)
     u64 act_off;                        // overflow slot of the active-segment list (LZ_DP_MAXACT - LZ_DP_ACT_LDS entries)
     u32 est_rows;                       // host-side guess of how many rows this DP will sweep (launch order only: longest first)
+    u32 problem;                        // which LzDpProblem of the launch this DP belongs to (0 in a single-problem launch)
 };
+
+// One launch can hold the DPs of several independent problems (the two strands of a query, the tweener windows of a
+// strand: lzgpu_gapped_extend_batch): each has its own bounding alignments and its own query; a job's indices
+// (left_align, list_start, ...) are relative to its problem's snapshot.
+struct LzDpProblem { LzDpSnapshot S; const u8* tdp; const u8* qdp; u32 tlen, qlen; };
 
 struct LzDpResult {
     s32 score; u32 end1, end2; u32 n_ops; u32 status; u32 truncated;

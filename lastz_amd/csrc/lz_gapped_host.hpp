@@ -29,6 +29,13 @@ struct LzDpExecutor {
                     std::vector<LzDpResult>& res, std::vector<std::vector<u32>>& ops) = 0;
 };
 
+// one problem's share of a multi-problem launch (HipDpExec::run_multi)
+struct LzDpBatchItem {
+    const LzHostSnapshot* snap; std::vector<LzDpJob>* jobs; std::vector<LzDpResult>* res; std::vector<std::vector<u32>>* ops;
+    const u8* qdp; u32 qlen;               // the problem's query and target: DP class codes on the device (a window: offset pointers)
+    const u8* tdp; u32 tlen;
+};
+
 struct LzGappedParams {
     const u8* t; u32 tlen;                 // host copies of the sequences (anchor reduction, rescoring)
     const u8* q; u32 qlen;

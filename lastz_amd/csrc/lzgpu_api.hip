@@ -10,6 +10,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
 #include "lz_lut.hpp"
@@ -25,6 +26,8 @@ int lz_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    static std::mutex m;                                        // (the problems of lzgpu_gapped_extend_batch run on threads of their own)
+    std::lock_guard<std::mutex> lk(m);
     g_ctx.last_error = buf;
     return code;
 }

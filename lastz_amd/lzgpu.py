@@ -40,7 +40,8 @@ class GappedArgs(C.Structure):
                 ("ydrop", C.c_int32), ("score_thresh", C.c_int32), ("traceback_bytes", C.c_uint32),
                 ("anchors", C.c_void_p), ("n_anchors", C.c_uint32), ("reduce", C.c_int32),
                 ("sep1", C.c_void_p), ("n_sep1", C.c_uint32), ("sep2", C.c_void_p), ("n_sep2", C.c_uint32),
-                ("strands_differ", C.c_int32), ("inhibit_trivial", C.c_int32)]
+                ("strands_differ", C.c_int32), ("inhibit_trivial", C.c_int32),
+                ("t_off", C.c_uint32), ("t_len", C.c_uint32), ("q_off", C.c_uint32), ("q_len", C.c_uint32)]
 
 
 class Counters(C.Structure):
@@ -58,7 +59,7 @@ ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end
 EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdown", "lzgpu_free",
            "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_table_save", "lzgpu_table_load", "lzgpu_device_copy",
-           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend",
+           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window", "lzgpu_dp_longest",
            "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode"]
@@ -106,6 +107,8 @@ class Lib:
             self.L.lzgpu_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
             self.L.lzgpu_query_upload.argtypes = [C.c_int32, C.c_void_p, C.c_uint32]
             self.L.lzgpu_target_upload.argtypes = [C.c_void_p, C.c_uint32]
+            self.L.lzgpu_gapped_extend_batch.argtypes = [C.POINTER(GappedArgs), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
             self.L.lzgpu_gapped_extend.argtypes = [C.POINTER(GappedArgs), C.POINTER(C.c_void_p),
                                                    C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
                                                    C.POINTER(C.c_uint64)]
@@ -238,11 +241,12 @@ class Lib:
         self._check(self.L.lzgpu_target_upload(_ptr(t), len(t)), "lzgpu_target_upload")
 
     # ---- B3
-    def gapped_extend(self, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400,
-                      score_thresh=3000, traceback_bytes=0, reduce=True, sep1=None, sep2=None, strands_differ=False, inhibit_trivial=False):
-        """sep1 / sep2: positions of the NUL bytes bounding the partitions of a [multi] target / query"""
+    def _gapped_args(self, keep, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400, score_thresh=3000,
+                     traceback_bytes=0, reduce=True, sep1=None, sep2=None, strands_differ=False, inhibit_trivial=False,
+                     t_off=0, t_len=0, q_off=0, q_len=0):
         a = GappedArgs()
         a.strands_differ, a.inhibit_trivial = int(strands_differ), int(inhibit_trivial)
+        a.t_off, a.t_len, a.q_off, a.q_len = t_off, t_len, q_off, q_len
         if sep1 is not None:
             sep1 = np.ascontiguousarray(sep1, dtype=np.uint32); a.sep1, a.n_sep1 = sep1.ctypes.data, len(sep1)
         if sep2 is not None:
@@ -258,17 +262,41 @@ class Lib:
         a.sub, a.gap_open, a.gap_extend, a.ydrop = sub.ctypes.data, gap_open, gap_extend, ydrop
         a.score_thresh, a.traceback_bytes = score_thresh, traceback_bytes
         a.anchors, a.n_anchors, a.reduce = anchors.ctypes.data, len(anchors), int(reduce)
+        keep += [sub, anchors, q, sep1, sep2]                  # alive until the call returns
+        return a
+
+    @staticmethod
+    def _gapped_out(L, out, n, ops, nops):
+        al = np.zeros(n, dtype=ALIGN_DTYPE)
+        op = np.zeros(nops, dtype=np.uint32)
+        if n:
+            C.memmove(_ptr(al), out, n * ALIGN_DTYPE.itemsize)
+        if nops:
+            C.memmove(_ptr(op), ops, nops * 4)
+        L.lzgpu_free(out); L.lzgpu_free(ops)
+        return al, op
+
+    def gapped_extend(self, sub, anchors, **kw):
+        """sep1 / sep2: positions of the NUL bytes bounding the partitions of a [multi] target / query;
+        t_off / t_len / q_off / q_len: a rectangle of the two sequences as the whole problem"""
+        keep = []
+        a = self._gapped_args(keep, sub, anchors, **kw)
         out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
         self._check(self.L.lzgpu_gapped_extend(C.byref(a), C.byref(out), C.byref(n), C.byref(ops), C.byref(nops)),
                     "lzgpu_gapped_extend")
-        al = np.zeros(n.value, dtype=ALIGN_DTYPE)
-        op = np.zeros(nops.value, dtype=np.uint32)
-        if n.value:
-            C.memmove(_ptr(al), out, n.value * ALIGN_DTYPE.itemsize)
-        if nops.value:
-            C.memmove(_ptr(op), ops, nops.value * 4)
-        self.L.lzgpu_free(out); self.L.lzgpu_free(ops)
-        return al, op
+        return self._gapped_out(self.L, out, n.value, ops, nops.value)
+
+    def gapped_extend_batch(self, sub, problems):
+        """problems: [dict(anchors=..., slot=... | q=..., ...)] sharing `sub` and the gap / y-drop parameters; the DPs of all
+        of them share the launches.  -> [(alignments, ops)] in the order of `problems`"""
+        keep, n = [], len(problems)
+        arr = (GappedArgs * n)()
+        for k, pr in enumerate(problems):
+            pr = dict(pr)
+            arr[k] = self._gapped_args(keep, sub, pr.pop("anchors"), **pr)
+        out = (C.c_void_p * n)(); no = (C.c_uint64 * n)(); ops = (C.c_void_p * n)(); nops = (C.c_uint64 * n)()
+        self._check(self.L.lzgpu_gapped_extend_batch(arr, n, out, no, ops, nops), "lzgpu_gapped_extend_batch")
+        return [self._gapped_out(self.L, out[k], no[k], ops[k], nops[k]) for k in range(n)]
 
     # ---- instrumentation
     def counters_reset(self):

@@ -157,3 +157,57 @@ def test_identical_sequences_get_the_trivial_alignment(gpu):
     q = t.copy(); q[777] = ord("A") if q[777] != ord("A") else ord("C")     # one base apart: an ordinary pair
     al, _ = gpu.gapped_extend(sub, segs.copy(), q=q)
     assert len(al) == 1
+
+
+def test_batch_of_problems_equals_one_call_each(gpu):
+    """lzgpu_gapped_extend_batch: both strands of a query (and a second query) as problems of one batch -- the DPs of
+    all of them share the launches -- give exactly what one lzgpu_gapped_extend call per problem gives"""
+    t, q = H.load_case("synth_overlap")
+    _, q2 = H.load_case("synth200k")
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    problems, single = [], []
+    for slot, qq in enumerate((q, seqio.revcomp(q), q2[:150000])):
+        gpu.query_upload(slot, qq)
+        hsps = gpu.seed_hit_search(masked, slot=slot)
+        segs = np.zeros(len(hsps), dtype=lzgpu.SEG_DTYPE)
+        segs["pos1"] = hsps["pos1"] - hsps["length"]; segs["pos2"] = hsps["pos2"] - hsps["length"]
+        segs["length"] = hsps["length"]; segs["s"] = hsps["score"]; segs["id"] = slot
+        problems.append(dict(anchors=segs, slot=slot))
+        single.append(gpu.gapped_extend(sub, segs, slot=slot))
+    gpu.counters_reset()
+    batch = gpu.gapped_extend_batch(sub, problems)
+    cb = gpu.counters()
+    assert len(batch) == 3 and sum(len(a) for a, _ in batch) > 10
+    for (al, ops), (sal, sops) in zip(batch, single):
+        assert len(al) == len(sal) and (al == sal).all() and (ops == sops).all()
+    assert cb["anchors_extended"] == sum(len(a) for a, _ in single) or cb["anchors_extended"] > 0
+    # mixed argument kinds: one problem by slot, one with the query passed as host bytes
+    two = gpu.gapped_extend_batch(sub, [problems[0], dict(anchors=problems[1]["anchors"], q=seqio.revcomp(q))])
+    for (al, ops), (sal, sops) in zip(two, single[:2]):
+        assert (al == sal).all() and (ops == sops).all()
+    with pytest.raises(Exception):                               # problems of a batch share the scoring
+        gpu.gapped_extend_batch(sub, [problems[0], dict(anchors=problems[1]["anchors"], slot=1, ydrop=5000)])
+
+
+def test_rectangle_of_the_sequences_as_a_problem(gpu):
+    """t_off / t_len / q_off / q_len: a window of the resident sequences is the whole problem (what the tweener does with
+    extract_subsequence, src/tweener.c:769-829) -- same alignments as the oracle on the cut-out pieces, window coordinates"""
+    t, q = H.load_case("synth_overlap")
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    gpu.query_upload(0, q)
+    wins = [(20000, 60000, 15000, 70000), (0, 50000, 0, 50000), (100000, len(t) - 100000, 90000, len(q) - 90000)]
+    problems, want = [], []
+    for (t0, tl, q0, ql) in wins:
+        tt, qq = t[t0:t0 + tl], q[q0:q0 + ql]
+        hsps, _ = lzo.seed_hit_search(lzo.Table(tt, lzo.seed()), qq, masked)
+        segs = lzo.hsps_to_segments(hsps, 0)
+        want.append(lzo.gapped_extend(tt, qq, sub, lzo.reduce_to_points(tt, qq, sub, segs))[:2])
+        problems.append(dict(anchors=segs.view(lzgpu.SEG_DTYPE), slot=0, t_off=t0, t_len=tl, q_off=q0, q_len=ql))
+    assert sum(len(a) for a, _ in want) > 5
+    for pr, (oal, oops) in zip(problems, want):                  # one at a time ...
+        pr1 = dict(pr); al, ops = gpu.gapped_extend(sub, pr1.pop("anchors"), **pr1)
+        assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
+    for (al, ops), (oal, oops) in zip(gpu.gapped_extend_batch(sub, problems), want):    # ... and as one batch
+        assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
