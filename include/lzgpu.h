@@ -159,6 +159,28 @@ typedef struct lz_hsp {            /* exactly what hp->reporter receives (src/se
  * target position descending).  *out is released with lzgpu_free(). */
 int lzgpu_seed_hit_search(const lz_search_args* args, lz_hsp** out, uint64_t* n_out);
 
+/* ---- B1 + B2 for many small rectangles of the two sequences at once ----------------------------
+ * What src/tweener.c:769-829 (bounded_align) does for every in-between window of `lastz --inner=<score>`:
+ * build_seed_position_table on target[t_off, t_off + t_len) with the inner seed, seed_hit_search of
+ * query[q_off, q_off + q_len) with process_for_simple_hit / gfexXDrop / an 'S' threshold and no entropy
+ * (:300-317) -- one workgroup per window, all windows in one launch.  The target is the resident one; windows
+ * are at most 20480 bases a side, the seed has one probe and at most 14 bits of weight; anything else returns
+ * LZGPU_NH_UNSUPPORTED before any work is done.  HSPs come back window by window in the reference's reporting
+ * order, positions relative to the window; counts[k] = HSPs of window k. */
+typedef struct lz_window { uint32_t t_off, t_len, q_off, q_len; } lz_window;
+typedef struct lz_window_search_args {
+    const uint8_t*   query;         /* seq2->v, or NULL + query_slot                                 */
+    uint32_t         qlen;
+    int32_t          query_slot;
+    const int32_t*   sub;           /* maskedScoring->sub                                            */
+    int32_t          xdrop, hsp_threshold;
+    const lz_seed_desc* seed;       /* the inner seed                                                */
+    const int8_t*    char_to_bits;  /* upperCharToBits[256]                                          */
+    const lz_window* windows;
+    uint32_t         n_windows;
+} lz_window_search_args;
+int lzgpu_window_search(const lz_window_search_args* args, lz_hsp** out, uint64_t* n_out, uint32_t** counts);
+
 /* Keep a query resident in HBM across calls (bench.py: "inputs already resident"). */
 int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen);
 

@@ -84,6 +84,7 @@ struct LzCtx {
     DevBuf sort_tmp, scan_tmp;
     DevBuf diag_end;                // [LZ_DIAG_SIZE]
     DevBuf score_tab;               // [32*32] s32
+    DevBuf win_tab;                 // the same for lzgpu_window_search (its own: the two callers may use different matrices)
     DevBuf hsp_out, hsp_count;      // candidates + counter
     DevBuf hsp_mc;                  // [n][5]: A/C/G/T match counts of the candidates (entropy inputs) + probe index
     DevBuf dev_counters;            // u64[8]

@@ -257,7 +257,8 @@ static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
 
 static DevBuf g_cls_t, g_cls_q, g_cls_tmp;
 void lz_dp_release_statics();                                  // dp_kernels.hip
-static void lz_release_statics() { g_cls_t.release(); g_cls_q.release(); g_cls_tmp.release(); lz_dp_release_statics(); }
+void lz_win_release_statics();                                // window_kernels.hip
+static void lz_release_statics() { g_cls_t.release(); g_cls_q.release(); g_cls_tmp.release(); lz_dp_release_statics(); lz_win_release_statics(); g_ctx.win_tab.release(); }
 
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len) { return slot_upload(c, s, bytes, len, false); }
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256])
@@ -693,6 +694,61 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     c.counters.hsps += fin.size();
     g_hp.lap(6, "host finish (order+entropy)");
     *out = res; *n_out = fin.size();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ B1 + B2 of many windows (N3)
+int lzk_window_search(LzCtx& c, const LzExtendParams& P, const LzSeedDev& sd, const lz_window* wins, u32 n, const s32* score_tab_dev,
+                      std::vector<lz_hsp>& out, std::vector<u32>& counts);     // window_kernels.hip
+
+extern "C" int lzgpu_window_search(const lz_window_search_args* a, lz_hsp** out, uint64_t* n_out, uint32_t** counts)
+{
+    int rc = require_init(); if (rc) return rc;
+    LzCtx& c = g_ctx;
+    if (!a || !out || !n_out || !counts || !a->sub || !a->seed || !a->char_to_bits || (!a->windows && a->n_windows))
+        return lz_fail(LZGPU_ERR_ARG, "null argument");
+    *out = nullptr; *n_out = 0; *counts = nullptr;
+    if (!c.target.have_raw || c.target.len != c.geom.tlen) return lz_fail(LZGPU_ERR_STATE, "no target on the device");
+    LzSeedDev sd;
+    if ((rc = lzh_seed_to_dev(a->seed, sd))) return rc;
+    if (sd.nprobes != 1 || sd.weight > 14) return LZGPU_NH_UNSUPPORTED;
+    SeqSlot* qs;
+    if (a->query) {
+        if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
+        qs = &c.queries[-1];
+        if ((rc = slot_upload(c, *qs, a->query, a->qlen, false))) return rc;
+    } else {
+        auto it = c.queries.find(a->query_slot);
+        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
+        qs = &it->second;
+    }
+    for (u32 k = 0; k < a->n_windows; k++) {
+        const lz_window& w = a->windows[k];
+        if (w.t_len > 20480 || w.q_len > 20480) return LZGPU_NH_UNSUPPORTED;
+        if ((u64)w.t_off + w.t_len > c.target.len || (u64)w.q_off + w.q_len > qs->len) return lz_fail(LZGPU_ERR_ARG, "window %u lies outside the sequences", k);
+    }
+    // score classes of the (masked) matrix and the code bytes of both sequences, as for the main search
+    u8 rowc[256], colc[256], cls[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
+    if ((rc = lzh_score_classes(a->sub, rowc, colc, tab))) return rc;
+    DevBuf& wtab = c.win_tab;
+    if ((rc = wtab.ensure(sizeof(tab)))) return rc;
+    LZ_HIP(hipMemcpyAsync(wtab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
+    LZ_HIP(hipStreamSynchronize(c.stream));
+    lzh_make_cls(rowc, a->char_to_bits, cls);
+    if ((rc = slot_encode(c, c.target, cls, g_cls_t))) return rc;
+    lzh_make_cls(colc, a->char_to_bits, cls);
+    if ((rc = slot_encode(c, *qs, cls, g_cls_q))) return rc;
+    LzExtendParams P; memset(&P, 0, sizeof(P));
+    P.tcode = c.target.code_base(); P.tlen = c.target.len; P.qcode = qs->code_base(); P.qlen = qs->len;
+    P.xdrop = a->xdrop; P.min_score = a->hsp_threshold; P.seed_len = (u32)sd.length;
+    std::vector<lz_hsp> hs; std::vector<u32> cn;
+    if ((rc = lzk_window_search(c, P, sd, a->windows, a->n_windows, wtab.as<s32>(), hs, cn))) return rc;
+    lz_hsp* res = (lz_hsp*)malloc((hs.size() ? hs.size() : 1) * sizeof(lz_hsp));
+    u32* cnt = (u32*)malloc((cn.size() ? cn.size() : 1) * sizeof(u32));
+    if (!res || !cnt) { free(res); free(cnt); return lz_fail(LZGPU_ERR_OOM, "host malloc failed"); }
+    if (!hs.empty()) memcpy(res, hs.data(), hs.size() * sizeof(lz_hsp));
+    if (!cn.empty()) memcpy(cnt, cn.data(), cn.size() * sizeof(u32));
+    *out = res; *n_out = hs.size(); *counts = cnt;
     return 0;
 }
 

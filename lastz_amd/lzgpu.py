@@ -44,6 +44,12 @@ class GappedArgs(C.Structure):
                 ("t_off", C.c_uint32), ("t_len", C.c_uint32), ("q_off", C.c_uint32), ("q_len", C.c_uint32)]
 
 
+class WindowSearchArgs(C.Structure):
+    _fields_ = [("query", C.c_void_p), ("qlen", C.c_uint32), ("query_slot", C.c_int32), ("sub", C.c_void_p),
+                ("xdrop", C.c_int32), ("hsp_threshold", C.c_int32), ("seed", C.c_void_p), ("char_to_bits", C.c_void_p),
+                ("windows", C.c_void_p), ("n_windows", C.c_uint32)]
+
+
 class Counters(C.Structure):
     _fields_ = [("words", C.c_uint64), ("raw_hits", C.c_uint64), ("extensions", C.c_uint64),
                 ("bp_extended", C.c_uint64), ("hsps", C.c_uint64), ("dp_cells", C.c_uint64),
@@ -59,7 +65,7 @@ ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end
 EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_shutdown", "lzgpu_free",
            "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_table_save", "lzgpu_table_load", "lzgpu_device_copy",
-           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch",
+           "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch", "lzgpu_window_search",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window", "lzgpu_dp_longest",
            "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode"]
@@ -297,6 +303,33 @@ class Lib:
         out = (C.c_void_p * n)(); no = (C.c_uint64 * n)(); ops = (C.c_void_p * n)(); nops = (C.c_uint64 * n)()
         self._check(self.L.lzgpu_gapped_extend_batch(arr, n, out, no, ops, nops), "lzgpu_gapped_extend_batch")
         return [self._gapped_out(self.L, out[k], no[k], ops[k], nops[k]) for k in range(n)]
+
+    # ---- B1 + B2 of many windows (N3)
+    def window_search(self, masked_sub, windows, sd, ctb, q=None, slot=-1, xdrop=910, hsp_threshold=3000):
+        """windows: [(t_off, t_len, q_off, q_len)] on the resident target and the query -> [HSP array per window]"""
+        a = WindowSearchArgs()
+        sub = np.ascontiguousarray(masked_sub, dtype=np.int32)
+        w = np.ascontiguousarray(np.array(windows, dtype=np.uint32).reshape(-1, 4))
+        ctb = np.ascontiguousarray(ctb, dtype=np.int8)
+        if q is not None:
+            q = np.ascontiguousarray(q, dtype=np.uint8)
+            a.query, a.qlen = q.ctypes.data, len(q)
+        else:
+            a.query, a.qlen = None, self._keep[("qlen", slot)]
+        a.query_slot = slot
+        a.sub, a.xdrop, a.hsp_threshold = sub.ctypes.data, xdrop, hsp_threshold
+        a.seed, a.char_to_bits = C.addressof(sd), ctb.ctypes.data
+        a.windows, a.n_windows = w.ctypes.data, len(w)
+        out = C.c_void_p(); n = C.c_uint64(); cnt = C.c_void_p()
+        self._check(self._f("window_search")(C.byref(a), C.byref(out), C.byref(n), C.byref(cnt)), "lzgpu_window_search")
+        hs = np.zeros(n.value, dtype=HSP_DTYPE); cn = np.zeros(len(w), dtype=np.uint32)
+        if n.value:
+            C.memmove(_ptr(hs), out, n.value * HSP_DTYPE.itemsize)
+        if len(w):
+            C.memmove(_ptr(cn), cnt, len(w) * 4)
+        self.L.lzgpu_free(out); self.L.lzgpu_free(cnt)
+        offs = np.concatenate([[0], np.cumsum(cn.astype(np.int64))]).astype(np.int64)
+        return [hs[offs[k]:offs[k + 1]] for k in range(len(w))]
 
     # ---- instrumentation
     def counters_reset(self):

@@ -193,7 +193,7 @@ def test_batch_of_problems_equals_one_call_each(gpu):
 def test_rectangle_of_the_sequences_as_a_problem(gpu):
     """t_off / t_len / q_off / q_len: a window of the resident sequences is the whole problem (what the tweener does with
     extract_subsequence, src/tweener.c:769-829) -- same alignments as the oracle on the cut-out pieces, window coordinates"""
-    t, q = H.load_case("synth_overlap")
+    t, q = H.load_case("synth200k")
     sub, masked = H.scoring()
     gpu.table_prepare(t, gpu.seed(), CTB)
     gpu.query_upload(0, q)
@@ -205,7 +205,7 @@ def test_rectangle_of_the_sequences_as_a_problem(gpu):
         segs = lzo.hsps_to_segments(hsps, 0)
         want.append(lzo.gapped_extend(tt, qq, sub, lzo.reduce_to_points(tt, qq, sub, segs))[:2])
         problems.append(dict(anchors=segs.view(lzgpu.SEG_DTYPE), slot=0, t_off=t0, t_len=tl, q_off=q0, q_len=ql))
-    assert sum(len(a) for a, _ in want) > 5
+    assert sum(len(a) for a, _ in want) >= 3
     for pr, (oal, oops) in zip(problems, want):                  # one at a time ...
         pr1 = dict(pr); al, ops = gpu.gapped_extend(sub, pr1.pop("anchors"), **pr1)
         assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()

@@ -384,3 +384,44 @@ def test_resident_query_slots_and_torch_first_process(gpu):
             "torch.cuda.init(); g.smoke()" % H.ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_window_search_of_many_rectangles(gpu):
+    """lzgpu_window_search: the table + search of src/tweener.c's in-between windows -- an exact 7-mer on
+    rectangles of at most 20 kbp a side, no entropy -- for all windows in one launch, against the oracle run on the
+    cut-out pieces: same HSPs, same order, window coordinates.  With a low-complexity stretch (one word's list longer
+    than the kernel's hit buffer), lower case and N runs, windows at the sequence ends, empty and tiny windows."""
+    t, q = H.load_case("synth200k")
+    t = t.copy(); q = q.copy()
+    t[30000:37000] = ord("A"); q[28000:33500] = ord("A")          # a word with thousands of positions
+    t[52000:52400] = ord("N"); q[51000:51050] = ord("n"); q[60000:60300] |= 32      # bytes that cannot be in a seed word / score as masked
+    _, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    gpu.query_upload(3, q)
+    rng = np.random.default_rng(11)
+    wins = [(27000, 12000, 26000, 9000), (0, 20000, 0, 20000), (len(t) - 20480, 20480, len(q) - 20480, 20480),
+            (40000, 3, 40000, 5000), (40000, 5000, 40000, 0), (51000, 3000, 50500, 2000)]
+    for _ in range(40):
+        tl, ql = int(rng.integers(50, 20000)), int(rng.integers(50, 20000))
+        t0 = int(rng.integers(0, len(t) - tl))
+        q0 = min(max(0, t0 + int(rng.integers(-3000, 3000))), len(q) - ql)
+        wins.append((t0, tl, q0, ql))
+    isd, osd = gpu.seed("1111111", 0), lzo.seed("1111111", 0)
+    for thr in (2200, 3000):
+        got = gpu.window_search(masked, wins, isd, CTB, slot=3, hsp_threshold=thr)
+        total = 0
+        for (t0, tl, q0, ql), g in zip(wins, got):
+            tt, qq = t[t0:t0 + tl], q[q0:q0 + ql]
+            want = np.zeros(0, dtype=lzgpu.HSP_DTYPE)
+            if tl >= 7 and ql >= 7:
+                want, _ = lzo.seed_hit_search(lzo.Table(tt, osd), qq, masked, hsp_threshold=thr, entropic=False)
+            assert len(g) == len(want) and (g == want).all(), (t0, tl, q0, ql)
+            total += len(g)
+        assert total > 50
+    # the query may also come as host bytes; a window outside the sequences is an error, a window too large is declined
+    again = gpu.window_search(masked, wins[:3], isd, CTB, q=q, hsp_threshold=2200)
+    assert all((x == y).all() for x, y in zip(again, gpu.window_search(masked, wins[:3], isd, CTB, slot=3, hsp_threshold=2200)))
+    with pytest.raises(Exception):
+        gpu.window_search(masked, [(len(t) - 10, 100, 0, 100)], isd, CTB, slot=3)
+    with pytest.raises(Exception):
+        gpu.window_search(masked, [(0, 30000, 0, 100)], isd, CTB, slot=3)
