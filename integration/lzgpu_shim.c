@@ -27,6 +27,8 @@
 #include "diag_hash.h"
 #include "capsule.h"
 #include "quantum.h"
+#include "tweener.h"
+#include "chain.h"
 #include "lzgpu.h"
 #include <sys/stat.h>
 #include <errno.h>
@@ -53,6 +55,10 @@ u64       ref_write_capsule_file (FILE* f, char* filename, seq* seq, u8* revNucs
 u32       ref_quantum_seed_hit_search (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end,
                                        const s8 charToBits[], seed* hitSeed, scoreset* scoring, score ballScore,
                                        hitprocessor processor, void* processorInfo);
+alignel*  ref_tweener_interpolate (alignel* a, seq* seq1, seq* seq2, int selfCompare, int inhibitTrivial,
+                                   const s8 charToBits[], seed* tweenSeed, scoreset* scoring, scoreset* maskedScoring,
+                                   tback* tb, score xDrop, int gappedAllBounds, score yDrop, int trimToPeak, score scoreThresh,
+                                   score diagPen, score antiPen, int scale, chainer connect, u32 windowSize);
 
 /* which host objects the device copy currently mirrors */
 static postable* devTable   = NULL;
@@ -193,6 +199,91 @@ static uint32_t* partition_separators (seq* s, uint32_t* n)
 	return v;
 	}
 
+/* ---- the tweener's in-between windows (lastz --inner=<score>, src/tweener.c), SURVEY 8(f) N3 ----
+ * tweener_interpolate walks the outer alignments and, for every gap, calls (through bounded_align, a static function)
+ * build_seed_position_table, seed_hit_search, reduce_to_chain and gapped_extend on copies of the two pieces.  The
+ * windows depend on the OUTER alignments only -- what is found inside one window never changes another (innerList is
+ * merged in at the very end, :465) -- so the reference routine is simply run three times with the three entry points
+ * in different roles, and all windows of the (query, strand) go to the device together:
+ *   pass 1  record   the hooks note every window (no HSPs are reported, so nothing is chained or extended)
+ *           -> lzgpu_window_search: table + search of all windows in one launch
+ *   pass 2  replay the HSPs, record the anchors the reference's own chaining hands to gapped_extend
+ *           -> lzgpu_gapped_extend_batch: the windows' DPs share their launches
+ *   pass 3  replay HSPs and alignments: the reference merges them as it always does
+ * A window is a copy (extract_subsequence, :1052): where it lies in the two sequences is found from the outer
+ * alignments (every window starts at the end of one or ends at the start of one, :424-447, :1016-1023) and
+ * checked by comparing the bytes, so a wrong guess is impossible and two places with equal bytes are equally good. */
+enum { twOff = 0, twRecord, twReplaySearch, twReplayAll };
+typedef struct twWindow
+	{
+	u32        tOff, tLen, qOff, qLen;
+	u32        hspStart, hspCount;      /* in twHsps */
+	lz_segment* anchors;  u32 numAnchors;
+	int        strandsDiffer;
+	lz_align*  aligns;  uint64_t numAligns;  uint32_t* ops;
+	} twWindow;
+static int       twMode = twOff, twFailed = false;
+static twWindow* twWin = NULL;   static u32 twNum = 0, twCap = 0, twCursor = 0;
+static lz_hsp*   twHsps = NULL;
+static alignel*  twOuter = NULL; static alignel* twHint = NULL;
+static seq*      twSeq1 = NULL;  static seq* twSeq2 = NULL;
+static hitprocinfo twHp;         static int twHaveHp = false;
+static const s8* twCharToBits = NULL;
+static struct { scoreset* scoring; int inhibitTrivial; score yDrop; sthresh scoreThresh; u32 tbSize; int have; } twGap;
+
+static int window_offsets (seq* w1, seq* w2, u32* tOff, u32* qOff)
+	{
+	alignel* a;  int pass, lap;
+	unspos   len1 = w1->len, len2 = w2->len;
+	for (lap=0 ; lap<2 ; lap++)                                 /* from the last match on, then from the start */
+		for (a=(lap==0)?twHint:twOuter ; a!=NULL ; a=a->next)
+			{
+			if ((lap == 1) && (a == twHint)) break;
+			for (pass=0 ; pass<2 ; pass++)
+				{
+				unspos o1, o2;
+				if (pass == 0)                                  /* the window ends where a begins */
+					{ if ((a->beg1 < len1) || (a->beg2 < len2)) continue;  o1 = a->beg1 - len1;  o2 = a->beg2 - len2; }
+				else                                            /* the window begins where a ends */
+					{ if ((a->end1 < 1) || (a->end2 < 1)) continue;  o1 = a->end1 - 1;  o2 = a->end2 - 1; }
+				if ((o1 + len1 > twSeq1->len) || (o2 + len2 > twSeq2->len)) continue;
+				if ((memcmp (twSeq1->v + o1, w1->v, len1) != 0) || (memcmp (twSeq2->v + o2, w2->v, len2) != 0)) continue;
+				*tOff = (u32) o1;  *qOff = (u32) o2;  twHint = a;
+				return true;
+				}
+			}
+	return false;
+	}
+
+static void tw_free (void)
+	{
+	u32 k;
+	for (k=0 ; k<twNum ; k++) { free (twWin[k].anchors);  lzgpu_free (twWin[k].aligns);  lzgpu_free (twWin[k].ops); }
+	free (twWin);  twWin = NULL;  twNum = twCap = twCursor = 0;
+	lzgpu_free (twHsps);  twHsps = NULL;
+	twMode = twOff;  twFailed = false;  twHaveHp = false;  twGap.have = false;
+	}
+
+static alignel* alignels_from (lz_align* al, uint64_t n, uint32_t* ops, seq* seq1, seq* seq2)
+	{
+	alignel* head = NULL, *last = NULL, *el;  uint64_t k;  u32 j;
+	for (k=0 ; k<n ; k++)                                      /* increasing start, src/gapped_extend.c:1475-1566 */
+		{
+		el = (alignel*) malloc_or_die ("lzgpu alignel", sizeof(alignel));
+		el->next = NULL;  el->isTrivial = false;  el->hspId = 0;
+		el->beg1 = al[k].beg1;  el->beg2 = al[k].beg2;  el->end1 = al[k].end1;  el->end2 = al[k].end2;
+		el->s = al[k].s;  el->seq1 = seq1->v;  el->seq2 = seq2->v;
+		el->script = edit_script_new ();
+		for (j=0 ; j<al[k].script_len ; j++)
+			{
+			uint32_t w = ops[al[k].script_off + j];
+			edit_script_add (&el->script, edit_op_operation(w), edit_op_repeat(w));
+			}
+		if (head == NULL) head = last = el;  else { last->next = el;  last = el; }
+		}
+	return head;
+	}
+
 /* ---- B1 ---- */
 
 postable* build_seed_position_table
@@ -204,8 +295,11 @@ postable* build_seed_position_table
 	int          rc;
 	char         cachePath[1200];
 
+	if ((twMode != twOff) && (seq->v != devTargetV))
+		return new_position_table (hitSeed->weight, start, e, step, true, true, false);    /* (a window of the tweener: nobody reads its table) */
+
 	/* the device holds ONE table: while the main target's table is live, any other table (the
-	   tweener's 7-mer tables on <=20 kbp windows, src/tweener.c:791) is built by the reference */
+	   tweener's 7-mer tables on <=20 kbp windows when they are not batched, src/tweener.c:791) is built by the reference */
 	if ((seq->len < min_target()) || (!fast_seed (hitSeed, &sd)) || (seq->fileType == seq_type_qdna)
 	 || (step < 1) || (e <= start) || (e > seq->len)
 	 || ((devTable != NULL) && (seq->v != devTargetV)))
@@ -306,6 +400,32 @@ u64 seed_hit_search
 	u64            basesHit = 0;
 	int            rc;
 
+	if (twMode == twRecord)                                     /* a window of the tweener: noted, searched later with all the others */
+		{
+		twWindow* w;  u32 tOff, qOff;
+		if (twFailed) return 0;
+		if ((processor != process_for_simple_hit) || (hp->gfExtend != gfexXDrop) || (hp->hspThreshold.t != 'S') || (hp->posFilter)
+		 || (hp->minMatches >= 0) || (hp->entropicHsp) || (hp->reportEntropy) || (selfCompare) || (bandWidth != 0) || (searchLimit != 0)
+		 || (start != 0) || ((end != 0) && (end != seq2->len)) || (seq1->len > 20480) || (seq2->len > 20480)
+		 || (!window_offsets (seq1, seq2, &tOff, &qOff)))
+			{ twFailed = true;  return 0; }
+		if (twNum == twCap) { twCap = 2*twCap + 64;  twWin = (twWindow*) realloc_or_die ("lzgpu windows", twWin, twCap * sizeof(twWindow)); }
+		w = &twWin[twNum++];  memset (w, 0, sizeof(*w));
+		w->tOff = tOff;  w->tLen = seq1->len;  w->qOff = qOff;  w->qLen = seq2->len;
+		if (!twHaveHp) { twHp = *hp;  twHaveHp = true;  twCharToBits = upperCharToBits; }
+		return 0;
+		}
+	if ((twMode == twReplaySearch) || (twMode == twReplayAll))  /* its HSPs, in the order the reference finds them */
+		{
+		twWindow* w = &twWin[twCursor++];
+		u32 i;
+		if ((twCursor > twNum) || (w->tLen != seq1->len) || (w->qLen != seq2->len)) suicide ("lzgpu: the tweener's windows changed between passes");
+		for (i=0 ; i<w->hspCount ; i++)
+			basesHit += (*hp->reporter) (hp->reporterInfo, twHsps[w->hspStart+i].pos1, twHsps[w->hspStart+i].pos2,
+			                             twHsps[w->hspStart+i].length, twHsps[w->hspStart+i].score);
+		return basesHit;
+		}
+
 	if ((pt != devTable) || (devTable == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
 	 || (processor != process_for_simple_hit) || (hp->gfExtend != gfexXDrop)
 	 || (hp->hspThreshold.t != 'S') || (hp->posFilter) || (hp->minMatches >= 0) || (hp->reportEntropy)
@@ -359,6 +479,35 @@ alignel* gapped_extend
 	u32            ix, j;
 	alignel*       head = NULL, *last = NULL, *el;
 	int            rc;
+
+	if (twMode == twReplaySearch)                               /* a window's anchors (chained by the reference): noted, extended later */
+		{
+		twWindow* w = &twWin[twCursor-1];
+		if (twFailed) return NULL;
+		if ((allBounds) || (!trimToPeak) || (scoreThresh.t != 'S') || (maxPairedBases != 0) || (tb == NULL) || (scoring->gapExtend <= 0)
+		 || ((twGap.have) && ((twGap.scoring != scoring) || (twGap.yDrop != yDrop) || (twGap.scoreThresh.s != scoreThresh.s))))
+			{ twFailed = true;  return NULL; }
+		if ((anchors == NULL) || (anchors->len == 0)) return NULL;
+		sort_segments (anchors, qSegmentsByDecreasingScore);    /* batched_segments, src/gapped_extend.c:1675 */
+		w->anchors = (lz_segment*) malloc_or_die ("lzgpu window anchors", ((size_t) anchors->len) * sizeof(lz_segment));
+		for (ix=0 ; ix<anchors->len ; ix++)
+			{
+			w->anchors[ix].pos1 = anchors->seg[ix].pos1;  w->anchors[ix].pos2   = anchors->seg[ix].pos2;
+			w->anchors[ix].s    = anchors->seg[ix].s;     w->anchors[ix].length = anchors->seg[ix].length;
+			w->anchors[ix].id   = anchors->seg[ix].id;
+			}
+		w->numAnchors = anchors->len;
+		w->strandsDiffer = (seq1->revCompFlags != seq2->revCompFlags);
+		twGap.scoring = scoring;  twGap.inhibitTrivial = inhibitTrivial;  twGap.yDrop = yDrop;  twGap.scoreThresh = scoreThresh;
+		twGap.tbSize = tb->size;  twGap.have = true;
+		return NULL;
+		}
+	if (twMode == twReplayAll)
+		{
+		twWindow* w = &twWin[twCursor-1];
+		if ((anchors != NULL) && (anchors->len != 0)) sort_segments (anchors, qSegmentsByDecreasingScore);   /* (the reference's side effect) */
+		return alignels_from (w->aligns, w->numAligns, w->ops, seq1, seq2);
+		}
 
 	/* gapped stage without a seed search (--segments=<file>): put the target on the device first */
 	if ((devTable == NULL) && ((seq1->v != devTargetV) || (seq1->len != devTargetLen))
@@ -432,4 +581,106 @@ alignel* gapped_extend
 	}
 	note ("gapped", "done on the GPU");
 	return head;
+	}
+
+/* ---- the tweener ---- */
+
+alignel* tweener_interpolate
+   (alignel* alignList, seq* seq1, seq* seq2, int selfCompare, int inhibitTrivial, const s8 charToBits[], seed* tweenSeed,
+	scoreset* scoring, scoreset* maskedScoring, tback* tb, score xDrop, int gappedAllBounds, score yDrop, int trimToPeak,
+	score scoreThresh, score diagPen, score antiPen, int scale, chainer connect, u32 windowSize)
+	{
+#define refTween() ref_tweener_interpolate (alignList, seq1, seq2, selfCompare, inhibitTrivial, charToBits, tweenSeed, scoring,    \
+	                                        maskedScoring, tb, xDrop, gappedAllBounds, yDrop, trimToPeak, scoreThresh, diagPen,      \
+	                                        antiPen, scale, connect, windowSize)
+	lz_seed_desc sd;
+	lz_window*   wins;
+	lz_window_search_args sa;
+	uint32_t*    counts = NULL;
+	uint64_t     nh = 0;
+	u32          k, nprob, at;
+	int          rc;
+	alignel*     res;
+
+	if ((alignList == NULL) || (getenv ("LZGPU_NO_WINDOW_BATCH") != NULL)
+	 || (devTargetV == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
+	 || (seq1->partition.p != NULL) || (seq2->partition.p != NULL) || (seq2->fileType == seq_type_qdna)
+	 || (!fast_seed (tweenSeed, &sd)) || (sd.num_probes != 1) || (sd.weight_bits > 14) || (windowSize > 20480)
+	 || (selfCompare) || (gappedAllBounds) || (!trimToPeak) || (tb == NULL) || (scoring->gapExtend <= 0))
+		{ note ("tweener", "reference path");  return refTween (); }
+
+	/* pass 1: which windows */
+	tw_free ();
+	twOuter = twHint = alignList;  twSeq1 = seq1;  twSeq2 = seq2;
+	twMode = twRecord;
+	res = refTween ();
+	if ((twFailed) || (res != alignList))
+		{ tw_free ();  note ("tweener", "declined, reference path");  return refTween (); }
+	if (twNum == 0) { tw_free ();  note ("tweener", "no windows");  return alignList; }
+
+	/* table + search of all of them */
+	wins = (lz_window*) malloc_or_die ("lzgpu windows", ((size_t) twNum) * sizeof(lz_window));
+	for (k=0 ; k<twNum ; k++)
+		{ wins[k].t_off = twWin[k].tOff;  wins[k].t_len = twWin[k].tLen;  wins[k].q_off = twWin[k].qOff;  wins[k].q_len = twWin[k].qLen; }
+	rc = lzgpu_query_upload (0x7FFF0001, seq2->v, seq2->len);     /* the strand's query, resident for both batches */
+	if (rc < 0) suicidef ("lzgpu_query_upload: %s", lzgpu_last_error());
+	memset (&sa, 0, sizeof(sa));
+	sa.query = NULL;  sa.qlen = seq2->len;  sa.query_slot = 0x7FFF0001;
+	sa.sub = (const int32_t*) twHp.scoring->sub;  sa.xdrop = twHp.xDrop;  sa.hsp_threshold = twHp.hspThreshold.s;
+	sa.seed = &sd;  sa.char_to_bits = twCharToBits;  sa.windows = wins;  sa.n_windows = twNum;
+	if (rc == 0) rc = lzgpu_window_search (&sa, &twHsps, &nh, &counts);
+	free (wins);
+	if (rc < 0) suicidef ("lzgpu_window_search: %s", lzgpu_last_error());
+	if (rc > 0) { tw_free ();  note ("tweener", "declined, reference path");  return refTween (); }
+	for (k=0,at=0 ; k<twNum ; k++) { twWin[k].hspStart = at;  twWin[k].hspCount = counts[k];  at += counts[k]; }
+	lzgpu_free (counts);
+	note ("tweener", "windows searched on the GPU");
+
+	/* pass 2: the reference chains every window's HSPs; its anchors are noted */
+	twMode = twReplaySearch;  twCursor = 0;
+	res = refTween ();
+	if ((twFailed) || (res != alignList) || (twCursor != twNum))
+		{ tw_free ();  note ("tweener", "declined, reference path");  return refTween (); }
+
+	/* the gapped stage of all windows with anchors */
+	for (k=0,nprob=0 ; k<twNum ; k++) if (twWin[k].numAnchors != 0) nprob++;
+	if (nprob != 0)
+		{
+		lz_gapped_args* ga  = (lz_gapped_args*) malloc_or_die ("lzgpu window problems", ((size_t) nprob) * sizeof(lz_gapped_args));
+		lz_align**      out = (lz_align**)  malloc_or_die ("lzgpu window problems", ((size_t) nprob) * sizeof(lz_align*));
+		uint64_t*       no  = (uint64_t*)   malloc_or_die ("lzgpu window problems", ((size_t) nprob) * sizeof(uint64_t));
+		uint32_t**      ops = (uint32_t**)  malloc_or_die ("lzgpu window problems", ((size_t) nprob) * sizeof(uint32_t*));
+		uint64_t*       nop = (uint64_t*)   malloc_or_die ("lzgpu window problems", ((size_t) nprob) * sizeof(uint64_t));
+		for (k=0,at=0 ; k<twNum ; k++)
+			{
+			lz_gapped_args* a;
+			if (twWin[k].numAnchors == 0) continue;
+			a = &ga[at++];  memset (a, 0, sizeof(*a));
+			a->query = NULL;  a->qlen = seq2->len;  a->query_slot = 0x7FFF0001;
+			a->sub = (const int32_t*) twGap.scoring->sub;  a->gap_open = twGap.scoring->gapOpen;  a->gap_extend = twGap.scoring->gapExtend;
+			a->ydrop = twGap.yDrop;  a->score_thresh = twGap.scoreThresh.s;  a->traceback_bytes = twGap.tbSize;
+			a->anchors = twWin[k].anchors;  a->n_anchors = twWin[k].numAnchors;  a->reduce = 0;
+			a->strands_differ = twWin[k].strandsDiffer;  a->inhibit_trivial = (twGap.inhibitTrivial != 0);
+			a->t_off = twWin[k].tOff;  a->t_len = twWin[k].tLen;  a->q_off = twWin[k].qOff;  a->q_len = twWin[k].qLen;
+			}
+		rc = lzgpu_gapped_extend_batch (ga, nprob, out, no, ops, nop);
+		if (rc < 0) suicidef ("lzgpu_gapped_extend_batch: %s", lzgpu_last_error());
+		if (rc == 0)
+			for (k=0,at=0 ; k<twNum ; k++)
+				{
+				if (twWin[k].numAnchors == 0) continue;
+				twWin[k].aligns = out[at];  twWin[k].numAligns = no[at];  twWin[k].ops = ops[at];  at++;
+				}
+		free (ga);  free (out);  free (no);  free (ops);  free (nop);
+		if (rc > 0) { tw_free ();  note ("tweener", "declined, reference path");  return refTween (); }
+		}
+	note ("tweener", "windows extended on the GPU");
+
+	/* pass 3: the reference merges what was found */
+	twMode = twReplayAll;  twCursor = 0;
+	res = refTween ();
+	tw_free ();
+	note ("tweener", "done on the GPU");
+	return res;
+#undef refTween
 	}

@@ -76,9 +76,10 @@ CASES = [
     ("extended", [T + "pseudocat.fa", T + "pseudopig.fa", "C=2", "W=8", "T=0"], "base_test.extended.lav", "lav", None,
      {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}, "gapped": {"done on the GPU": 6}}),
     ("interpolated", [T + "pseudocat.fa", T + "pseudopig.fa", "C=2", "W=8", "T=0", "H=2200"], "base_test.interpolated.lav", "lav", None,
-     # the tweener's 15 inner windows (7-mer tables on <= 20 kbp, src/tweener.c:769-829) take the reference's routines
-     {"table": {"built on the GPU": 1, "reference path": 15}, "search": {"done on the GPU": 6, "reference path": 15},
-      "gapped": {"done on the GPU": 6, "reference path": 6}}),
+     # the tweener's 15 inner windows (7-mer tables on <= 20 kbp, src/tweener.c:769-829): searched and extended as
+     # batches, one of each per (query, strand) -- lzgpu_window_search, lzgpu_gapped_extend_batch
+     {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}, "gapped": {"done on the GPU": 6},
+      "tweener": {"windows searched on the GPU": 6, "windows extended on the GPU": 6, "done on the GPU": 6}}),
     ("stdin2", [T + "pseudocat.fa", "C=3", "W=8", "T=0"], None, None, "pseudopig.fa",
      {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}}),
     ("2bit1", [T + "pseudopig.2bit/pig2", T + "pseudocat.fa", "C=2", "W=8", "T=0"], None, None, None,
@@ -142,7 +143,8 @@ def test_base_test(sandbox, name, args, golden, how, stdin, expect):
                 assert seen.get(stage, {}).get(how_, 0) == n, (stage, seen)
     # whatever ran, nothing failed over silently: every stage line is one of the known outcomes
     known = {"built on the GPU", "done on the GPU", "reference path", "declined, reference path", "loaded from the table cache",
-             "copied to the host for a reference routine", "unit of another rank", "shared with the other ranks", "received from rank 0"}
+             "copied to the host for a reference routine", "unit of another rank", "shared with the other ranks", "received from rank 0",
+             "windows searched on the GPU", "windows extended on the GPU", "no windows"}
     assert all(h in known for st in seen.values() for h in st), seen
 
 
