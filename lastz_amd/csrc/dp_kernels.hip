@@ -122,13 +122,19 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
     }
 };
 
-__global__ void __launch_bounds__(LZ_DP_LANES)
+#ifndef LZ_DP_WPE
+#define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow: six DPs of four waves per CU
+#endif
+__global__ void __launch_bounds__(LZ_DP_LANES, LZ_DP_WPE)
 k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
-        const s32* __restrict__ tab_g, LzDpResult* __restrict__ res)
+        const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
 {
+    // LDS per DP decides how many DPs share a CU (160 KiB): 25.5 KiB of sweep row and state + the rows of the class
+    // table the matrix really has (dynamic: 1 KiB for HOXD70's 8 row classes) = six DPs per CU (round 2: 34 KiB with
+    // a full 32 x 32 table and 32-bit mask stamps, four per CU)
     __shared__ LzDpShared sh;
-    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
-    for (int k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
+    extern __shared__ __align__(16) s32 tab[];
+    for (u32 k = threadIdx.x; k < tab_rows * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
     __syncthreads();
     const u32 j = job_ids[blockIdx.x];
     GpuPhases x;
@@ -196,6 +202,7 @@ struct HipDpExec : LzDpExecutor {
     explicit HipDpExec(LzCtx& ctx) : c(ctx) {}
 
     u64 wide_runs = 0;
+    u32 tab_rows = LZ_NCLASS;                                  // row classes of the score matrix in use (k_ydrop's dynamic LDS)
     const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
     // Traceback slots.  A retry gives every DP the same (larger) slot; the first try sizes each DP's slot from the
     // host's guess of the rows it will sweep (est_rows, lz_gapped_host.cpp: the deferred anchors around the DP's
@@ -246,8 +253,8 @@ struct HipDpExec : LzDpExecutor {
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.timer.begin("k_ydrop", c.stream);
-            hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
-                               problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>());
+            hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
+                               problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
         c.timer.end(c.stream);
         LZ_HIP(hipGetLastError());
@@ -551,6 +558,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     ex.P.ydrop_tail = a0.ydrop / a0.gap_extend + 6;                      // :3484-3492
     ex.P.tb_len = a0.traceback_bytes ? a0.traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
     ex.slot_tb = g_dp_slot_tb;
+    { u32 nr = 0; for (int b = 0; b < 256; b++) if (rowc[b] >= nr) nr = (u32)rowc[b] + 1; ex.tab_rows = nr; }
 
     DpRendezvous R(ex, (int)n);
     std::vector<std::vector<lz_align>> al(n); std::vector<std::vector<u32>> op(n); std::vector<LzGappedStats> st(n); std::vector<int> rcs(n, 0);

@@ -45,7 +45,10 @@
 #define LZ_UNROLL
 #endif
 #define LZ_DP_SERIAL_FILL 4           // overhang cells lane 0 stores itself at row end
-#define LZ_DP_ACT_LDS 32              // active segments kept in LDS (one more DP per CU than with all of them there)
+#ifndef LZ_DP_STAMP_PERIOD
+#define LZ_DP_STAMP_PERIOD 65535        // rows after which the 16-bit mask stamps of the LDS ring start over (tests: a small period)
+#endif
+#define LZ_DP_ACT_LDS 16              // active segments kept in LDS (the rest in the job's HBM slot: LDS bytes per DP decide how many DPs share a CU)
 #define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
@@ -107,15 +110,26 @@ struct LzDpActive { s32 align, seg; u32 x, last_row; s32 type; s32 filter; };
 // The sweep row is a ring indexed by column & (RING-1).  Two homes for it: arrays in the DP's LDS block (the
 // normal kernel), or a slot in HBM behind pointers (k_ydrop_wide: the rare bands wider than the LDS ring --
 // small gap-extension penalties, huge y-drops; the same code, flat loads instead of ds loads).
+// Mask stamps.  The reference stamps mask[col] = row (:3706) and a cell is masked when its stamp is the current row.
+// In LDS a stamp is 16 bits (the ring's LDS bytes decide how many DPs share a CU: 34 KiB -> 27 KiB per DP, four -> six
+// DPs per CU): stamp(row) = 1 + (row - 1) mod 65535, never 0 (= no stamp), and the ring's stamps are cleared whenever
+// the stamp wraps to 1 again (lz_dp_run, before the row's own stamps are written), so that a stamp left behind
+// 65535 rows ago cannot be taken for the current row.
 template <u32 W> struct LzDpRingLds {
     static constexpr u32 RING = W;
+    static constexpr bool STAMP_WRAPS = true;
+    typedef unsigned short stamp_t;
+    static LZ_HD u32 stamp(u32 row) { return 1u + (row - 1u) % (u32)LZ_DP_STAMP_PERIOD; }
     s32 cc[W], dd[W];                     // C[row][col], D[row+1][col]
-    u32 mk[W];                            // mask stamps (= row number), :3706
+    stamp_t mk[W];                        // mask stamps
     u8  lk[W];                            // traceback link of the current row
     u8  bb[W];                            // B (query) score classes of the band's columns
 };
 struct LzDpRingHbm {
     static constexpr u32 RING = LZ_DP_WIDEW;
+    static constexpr bool STAMP_WRAPS = false;
+    typedef u32 stamp_t;
+    static LZ_HD u32 stamp(u32 row) { return row; }
     s32 *cc, *dd; u32* mk; u8 *lk, *bb;
     static constexpr size_t SLOT_BYTES = (size_t)LZ_DP_WIDEW * 14;
     LZ_HD void bind(u8* slot) { cc = (s32*)slot; dd = cc + LZ_DP_WIDEW; mk = (u32*)(dd + LZ_DP_WIDEW); lk = (u8*)(mk + LZ_DP_WIDEW); bb = lk + LZ_DP_WIDEW; }
@@ -283,7 +297,7 @@ LZ_HD void lz_dp_update_lr(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJo
 
 // build_active_seg, src/gapped_extend.c:4992-5035: only cells inside [LY,RY] are stamped (that
 // also keeps the ring free of aliases: RY - LY < MAXW)
-template <class SH> LZ_HD void lz_dp_stamp(SH& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = row; }
+template <class SH> LZ_HD void lz_dp_stamp(SH& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = (typename SH::stamp_t)SH::stamp(row); }
 template <class SH> LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, SH& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive& act)
 {
     const LzDpSeg& sg = S.segs[act.seg];
@@ -295,7 +309,7 @@ template <class SH> LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, SH& sh,
         u32 horz_end = (!J.reversed) ? sg.e2 - J.anchor2 : J.anchor2 - sg.b2;
         u32 i_min = c.LY > act.x ? c.LY : act.x;
         u32 i_max = c.RY < horz_end ? c.RY : horz_end;
-        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = c.row;
+        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = (typename SH::stamp_t)SH::stamp(c.row);
     }
 }
 
@@ -486,6 +500,8 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             ct.prevLY = ct.LY;
             lz_dp_update_lr(x, S, ct, J);
             q3 = LZ_PHASE_CLOCK();
+            if (SH::STAMP_WRAPS && ct.row > 1 && SH::stamp(ct.row) == 1u)          // the 16-bit stamps start over: none of the old ones may survive
+                for (u32 k = 0; k < SH::RING; k++) sh.mk[k] = 0;
             lz_dp_update_active(x, S, sh, ct, J, P.act_arena + J.act_off);
             q4 = LZ_PHASE_CLOCK();
             if (ct.done) return;
@@ -526,6 +542,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         row = x.uni(sh.row); LY0 = x.uni(sh.LY); RYi = x.uni(sh.ry_iter); cpl = x.uni(sh.cpl); best0 = x.uni(sh.best); trow_cur = x.uni(sh.trow_cur);
         swept = true;
         const bool any_active = sh.n_act != 0;
+        const u32 row_stamp = SH::stamp(row);
         const u32 arow = sh.aa[(row - 1) & (LZ_DP_LANES - 1)];
         const s32* trow_tab = tab + (arow << 5);
 
@@ -552,7 +569,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                         const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
                         const s32 d = vdd[k];
                         c_left = vcc[k];
-                        const bool masked = any_active && vmk[k] == row;
+                        const bool masked = any_active && vmk[k] == row_stamp;
                         if (masked) { A = LZ_DP_NEGINF; K = 0; cut = 1; }
                         else {
                             const s32 a2 = A - gapE;
@@ -587,7 +604,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                         s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
                         s32 d = vdd[k];
                         c_left = vcc[k];
-                        const bool masked = any_active && vmk[k] == row;
+                        const bool masked = any_active && vmk[k] == row_stamp;
                         u32 link;
                         if (masked) { link = 0x80; c = LZ_DP_NEGINF; d = LZ_DP_NEGINF; i = LZ_DP_NEGINF; }
                         else if (d > c || i > c) {

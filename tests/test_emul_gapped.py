@@ -128,3 +128,18 @@ def test_speculation_windows_on_random_obstacle_courses(L, seed):
     stats = [_check(L, t, q, window=w) for w in (1, 1024)]
     assert stats[0]["rounds"] >= stats[1]["rounds"]
     assert stats[0]["anchors_extended"] == stats[1]["anchors_extended"]
+
+
+def test_sixteen_bit_mask_stamps_start_over(L):
+    """The sweep row's mask stamps are 16 bits in LDS and start over every LZ_DP_STAMP_PERIOD rows (65535), the ring's
+    stamps being cleared at that moment.  Built with a period of 37 rows the same code starts over hundreds of times
+    inside every DP of a case full of overlapping alignments (masked cells on most rows): still the oracle's alignments,
+    scripts and cell counts."""
+    so = H.build_emul(tag="stamp37", flags=["-DLZ_DP_STAMP_PERIOD=37"])
+    lib = C.CDLL(so)
+    lib.emul_gapped_extend.argtypes = L.emul_gapped_extend.argtypes
+    t, q = H.load_case("synth_overlap")
+    tot = _check(lib, t, q)
+    assert tot["anchors_extended"] > 5
+    t, q = H.load_case("adversarial")
+    _check(lib, t[:30000], q[:30000])
