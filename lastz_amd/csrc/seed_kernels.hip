@@ -501,7 +501,7 @@ void lz_phase_clocks_print()
 void lz_phase_clocks_print() {}
 #endif
 #ifndef LZ_PP_TPB
-#define LZ_PP_TPB    512
+#define LZ_PP_TPB    1024                            // one workgroup per CU: 128 KiB of staging for a tile of 16384 hits (runs of 64 records per partition)
 #endif
 #define LZ_PP_WAVES  (LZ_PP_TPB / 64)
 #define LZ_SC_ROUNDS 4                               // k_scan_hits: rounds of 64 hits a wave takes per span

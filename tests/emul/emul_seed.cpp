@@ -283,3 +283,40 @@ extern "C" int emul_sort4_selftest(uint32_t seed, uint32_t n)
     std::sort(b.begin(), b.end(), less);
     return a == b ? 0 : 1;
 }
+
+// lzh_finish_hsps with many candidates (the multi-threaded path: chunk sorts, merge levels, entropy factors behind
+// spin barriers) against a plain serial statement of the same thing.  Returns the number of differences.
+extern "C" int emul_finish_selftest(uint32_t seed, uint32_t n)
+{
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 11;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 9); };
+    LzSeedDev sd; memset(&sd, 0, sizeof(sd)); sd.length = 19; sd.weight = 24; sd.nprobes = 13;
+    std::vector<LzHspRec> recs(n); std::vector<u32> mc((size_t)n * 5);
+    for (uint32_t i = 0; i < n; i++) {
+        LzHspRec& r = recs[i];
+        r.seed_pos2 = 100 + rnd() % (n / 4 + 50);              // many candidates per query position
+        r.seed_pos1 = 100 + rnd() % 100000; r.length = 30 + rnd() % 300; r.end1 = r.seed_pos1 + rnd() % 100; r.score = 2500 + (s32)(rnd() % 9000);
+        u32 left = r.length;
+        for (int k = 0; k < 4; k++) { const u32 c = rnd() % (left / 2 + 1); mc[5 * (size_t)i + k] = c; left -= c; }
+        mc[5 * (size_t)i + 4] = rnd() % 13;
+    }
+    int8_t ctb[256]; memset(ctb, -1, 256);
+    std::vector<lz_hsp> got; std::vector<u64> ord;
+    if (lzh_finish_hsps(recs.data(), n, nullptr, nullptr, sd, ctb, 3000, 1, got, mc.data(), &ord)) return -1;
+    // serial reference
+    std::vector<u32> ix(n); for (uint32_t i = 0; i < n; i++) ix[i] = i;
+    auto key = [&](u32 i) { return std::make_tuple(recs[i].seed_pos2, mc[5 * (size_t)i + 4], ~recs[i].seed_pos1); };
+    std::stable_sort(ix.begin(), ix.end(), [&](u32 a, u32 b) { return key(a) < key(b); });
+    std::vector<lz_hsp> want;
+    for (u32 i : ix) {
+        const LzHspRec& r = recs[i]; s32 sim = r.score;
+        if (sim >= 3000 && (s64)sim <= 9000) sim = (s32)(sim * lzh_entropy_from_counts((int)mc[5 * (size_t)i], (int)mc[5 * (size_t)i + 1], (int)mc[5 * (size_t)i + 2], (int)mc[5 * (size_t)i + 3], (int)r.length));
+        if (sim < 3000) continue;
+        const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+        want.push_back({ r.end1, (u32)((s32)r.end1 - diag), r.length, sim });
+    }
+    if (want.size() != got.size()) return 1 + (int)want.size();
+    int bad = 0;
+    for (size_t k = 0; k < want.size(); k++) if (memcmp(&want[k], &got[k], sizeof(lz_hsp)) != 0) bad++;
+    return bad;
+}

@@ -156,3 +156,11 @@ def test_lut_scans_with_dense_specials_and_short_sequences(em, seed):
     _check(em, t[:300], q[:200], pattern="11111111", wt=0, hsp_threshold=800)          # everything within reach of an end
     _check(em, t, q, xdrop=374, hsp_threshold=1500)         # three bases after a maximum set inside a group can lose 375 > xDrop: not eligible
     assert _mode(em) == 2
+
+
+def test_host_finish_with_many_candidates(em):
+    """the threaded path of lzh_finish_hsps (>= 16384 candidates: chunk sorts, merge levels, entropy factors on up to
+    16 threads) against a serial statement; ties in (query position, probe) are ordered by target position"""
+    em.L.emul_finish_selftest.restype = C.c_int
+    for seed, n in ((1, 16384), (2, 50001), (3, 200000)):
+        assert em.L.emul_finish_selftest(seed, n) == 0
