@@ -378,6 +378,10 @@ def run_single(a, torch, lib):
     cli = None
     gpu_bin = os.path.join(ROOT, "integration", "_build", "lastz_gpu")
     if not a.no_cli and os.path.exists(gpu_bin):
+        # the CLI is a process of its own: this one first lets go of its device buffers (~60 GiB of chunk buffers and
+        # DP arenas), as they would not be there in a stand-alone run -- a fresh process pays for device memory by
+        # the GiB when another process holds most of what the driver keeps ready
+        lib.shutdown()
         with tempfile.TemporaryDirectory() as d:
             tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
             seqio.write_fasta(tf, [("target", target)]); seqio.write_fasta(qf, [("query", query)])

@@ -72,6 +72,9 @@ int lzgpu_seed_from_pattern(const char* pattern, int with_trans, lz_seed_desc* o
 
 /* 0 if a gfx950 device is usable by this process, else LZGPU_ERR_NO_DEVICE. */
 int lzgpu_probe(void);
+/* lzgpu_init on a thread of its own (returns at once); any later call of the library waits for it to finish.  For a
+ * host that has seconds of its own start-up work before it first needs the device (integration/lzgpu_shim.c). */
+void lzgpu_init_async(int device_index);
 /* Bind this process to one device (one process per GPU; LOCAL_RANK under torch.distributed). */
 int lzgpu_init(int device_index);
 void lzgpu_shutdown(void);

@@ -11,6 +11,8 @@
 #include <math.h>
 #include <algorithm>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
 #include "lz_lut.hpp"
@@ -129,7 +131,7 @@ extern "C" int lzgpu_probe(void)
     return 0;
 }
 
-extern "C" int lzgpu_init(int device_index)
+static int lz_init_locked(int device_index)
 {
     if (g_ctx.inited && (device_index < 0 || device_index == g_ctx.device)) return 0;
     if (g_ctx.inited) return lz_fail(LZGPU_ERR_STATE, "already bound to device %d", g_ctx.device);
@@ -157,6 +159,28 @@ extern "C" int lzgpu_init(int device_index)
     g_ctx.device = device_index;
     g_ctx.inited = true;
     return 0;
+}
+
+// lzgpu_init_async: the same on a detached thread; every path into lzgpu_init first waits for it (and so does exit():
+// the runtime must not be torn down under a thread that is still bringing it up)
+static std::mutex g_init_mutex;
+static std::atomic<int> g_async_state{0};                      // 0: never asked, 1: running, 2: finished
+static void lz_wait_async() { while (g_async_state.load(std::memory_order_acquire) == 1) std::this_thread::yield(); }
+extern "C" void lzgpu_init_async(int device_index)
+{
+    int expect = 0;
+    if (!g_async_state.compare_exchange_strong(expect, 1)) return;
+    atexit(lz_wait_async);
+    std::thread([device_index]() {
+        { std::lock_guard<std::mutex> lk(g_init_mutex); (void)lz_init_locked(device_index); }
+        g_async_state.store(2, std::memory_order_release);
+    }).detach();
+}
+extern "C" int lzgpu_init(int device_index)
+{
+    lz_wait_async();
+    std::lock_guard<std::mutex> lk(g_init_mutex);
+    return lz_init_locked(device_index);
 }
 
 extern "C" void lzgpu_shutdown(void)

@@ -842,7 +842,7 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
     }
 }
 
-// grid of k_scan_hits for n hits, and the geometry of its task list: one region per wave, room for 1/8 of the
+// grid of k_scan_hits for n hits, and the geometry of its task list: one region per wave, room for 1/32 of the
 // wave's hits + 64 (64 B each; the usual load is ~3 %); a hit that finds its region full is left to phase B
 static int lz_scan_tpb(int mode)
 {
@@ -858,7 +858,7 @@ static void lz_scan_geometry(LzCtx& c, int mode, u64 n, u32& grid, u32& n_region
     const u64 nspans = (n + 64u * LZ_SC_ROUNDS - 1) / (64u * LZ_SC_ROUNDS), want = (nspans + wpg - 1) / wpg;
     grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
     n_regions = grid * wpg;
-    region_cap = (u32)std::min<u64>(n / 8 / n_regions + 64, 1u << 20);
+    region_cap = (u32)std::min<u64>(n / 32 / n_regions + 64, 1u << 20);   // (64 B each; ~3 % of the hits become tasks: 1/32 of them fit, 2 GiB less to allocate than with 1/8)
     static const char* force = getenv("LZGPU_TASK_REGION_CAP");  // test hook: tiny regions, so that hits find theirs full
     if (force && atoi(force) > 0) region_cap = (u32)atoi(force);
 }
