@@ -175,6 +175,18 @@ static int unit_is_mine (seq* seq2)
 	return ((int) (ix % (u32) mgWorld) == mgRank);                      /* no plan: round robin */
 	}
 
+/* LZGPU_UNIT_MARKERS=1 (the launcher sets it for the line-oriented output formats): a comment line on standard
+ * output names the unit whose records follow, so that the launcher can put the ranks' records back in file order
+ * without parsing sequence names.  The reference writes a unit's records after this point and before the next
+ * unit's search (src/lastz.c:3053-3452), through the same stdio buffer. */
+static void unit_marker (seq* seq2)
+	{
+	static int want = -1;
+	if (want < 0) { char* e = getenv ("LZGPU_UNIT_MARKERS");  want = ((e != NULL) && (e[0] == '1')); }
+	if (!want) return;
+	fprintf (stdout, "#lzgpu-unit %u %d\n", (seq2->contig >= 1)? seq2->contig : 1, ((seq2->revCompFlags & rcf_rev) != 0)? 1 : 0);
+	}
+
 static int fast_seed (seed* hitSeed, lz_seed_desc* sd)
 	{
 	int i, j, nf, np;
@@ -447,6 +459,15 @@ u64 seed_hit_search
 		return basesHit;
 		}
 
+	/* one process per GPU: a unit of another rank yields nothing here, whichever routine would have searched it
+	 * (the tweener's windows are cut from a unit this rank owns: src/tweener.c:1073-1075 gives them no file) */
+	if (seq2->fileType != seq_type_nofile)
+		{
+		if (!unit_is_mine (seq2))
+			{ note ("search", "unit of another rank");  empty_diag_hash ();  return 0; }
+		unit_marker (seq2);
+		}
+
 	if ((pt != devTable) || (devTable == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
 	 || (processor != process_for_simple_hit) || (hp->gfExtend != gfexXDrop)
 	 || (hp->hspThreshold.t != 'S') || (hp->posFilter) || (hp->minMatches >= 0) || (hp->reportEntropy)
@@ -457,9 +478,6 @@ u64 seed_hit_search
 		{ note ("search", "reference path");  host_table_needed (pt);
 		  return ref_seed_hit_search (seq1, pt, seq2, start, end, selfCompare, upperCharToBits, hitSeed,
 		                              searchLimit, reportSearchLimit, bandWidth, processor, processorInfo); }
-
-	if (!unit_is_mine (seq2))
-		{ note ("search", "unit of another rank");  empty_diag_hash ();  return 0; }
 
 	memset (&a, 0, sizeof(a));
 	a.query = seq2->v;  a.qlen = seq2->len;  a.query_slot = -1;

@@ -17,7 +17,9 @@ every rank: about 1 s of host time per 50 Mbp of query, whoever owned it.)  Quer
 (2bit, hsx, files with actions other than the ones passed through) fall back to "every rank reads everything".
 
 A rank produces the stanzas of its own units only; this module puts them back in the reference's order: queries in
-file order, + strand before - strand (src/lastz.c:1592-1691).  LAV only (checked before anything is launched).
+file order, + strand before - strand (src/lastz.c:1592-1691).  LAV is merged by its stanzas; MAF, AXT, general, cigar,
+sam and differences by unit markers the bound binary prints (LZGPU_UNIT_MARKERS); anything else is refused before
+anything is launched.
 """
 import argparse
 import mmap
@@ -166,14 +168,73 @@ def _rename_query(unit, old, new):
     return "\n".join(lines)
 
 
-def check_supported(target, args):
-    """what the merger cannot put back together is refused before any rank starts"""
+_MARKER = re.compile(r"^#lzgpu-unit (\d+) ([01])\n", re.M)
+_AXT_HEAD = re.compile(r"^\d+( \S+ \d+ \d+ \S+ \d+ \d+ [+-])", re.M)
+
+
+def output_format(args):
+    """the --format the command line asks for ('lav' when it names none), lower case"""
+    fmt = "lav"
     for a in args:
+        a = a.lower()
         if a.startswith("--format=") or a.startswith("--output-format="):
             fmt = a.split("=", 1)[1]
-            if fmt not in ("lav", "LAV"):
-                raise ValueError("lastz_amd.multi merges LAV output only (got %s); run the formats the launcher does not "
-                                 "know through a single lastz_gpu process" % a)
+        elif re.match(r"--(lav|maf|axt|waxt|cigar|sam|softsam|rdotplot|text|differences|general|mapping|gfa|blastn|paf)", a):
+            fmt = a[2:].replace("=", ":", 1)
+    return fmt
+
+
+def line_oriented(fmt):
+    """formats whose output is a header followed by self-contained records, nothing at the end and no state carried from
+    one unit to the next beyond AXT's running number (src/maf.c, src/axt.c, src/genpaf.c, src/cigar.c, src/sam.c)"""
+    base = re.split(r"[:+-]", fmt.lstrip("~"), 1)[0]
+    return base in ("maf", "axt", "waxt", "general", "mapping", "cigar", "sam", "softsam", "differences")
+
+
+def split_marked(text):
+    """output written with LZGPU_UNIT_MARKERS=1 -> (header, [((contig, strand), records)])"""
+    ms = list(_MARKER.finditer(text))
+    if not ms:
+        return text, []
+    units = []
+    for i, m in enumerate(ms):
+        e = ms[i + 1].start() if i + 1 < len(ms) else len(text)
+        units.append(((int(m.group(1)), int(m.group(2))), text[m.end():e]))
+    return text[:ms[0].start()], units
+
+
+def merge_marked(texts, fmt="maf", rename=None):
+    """ranks' outputs in a line-oriented format -> what one process prints: rank 0's header, then every unit's
+    records in file order (queries in file order, + strand before -).  AXT's running alignment number
+    (src/axt.c:271-288) is counted again over the merged list."""
+    head, allu = None, []
+    for r, t in enumerate(texts):
+        h, u = split_marked(t)
+        if rename and rename[r][0] != rename[r][1]:
+            h = h.replace(rename[r][0], rename[r][1])             # the command line in the header comments
+        head = h if head is None else head
+        allu += u
+    keys = [k for k, _ in allu]
+    assert len(set(keys)) == len(keys), "a unit was produced by two ranks"
+    allu.sort(key=lambda ku: ku[0])
+    body = "".join(u for _, u in allu)
+    if fmt.lstrip("~w").startswith("axt"):
+        n = [-1]
+
+        def renumber(m):
+            n[0] += 1
+            return "%d%s" % (n[0], m.group(1))
+        body = _AXT_HEAD.sub(renumber, body)
+    return (head or "") + body
+
+
+def check_supported(target, args):
+    """what the merger cannot put back together is refused before any rank starts"""
+    fmt = output_format(args)
+    if fmt != "lav" and not line_oriented(fmt):
+        raise ValueError("lastz_amd.multi merges LAV, MAF, AXT, general, cigar, sam and differences output (got %s); run "
+                         "the formats the launcher does not know through a single lastz_gpu process" % fmt)
+    for a in args:
         if a.startswith("--output=") or a == "--markend":
             raise ValueError("lastz_amd.multi collects the ranks' standard output: %s is not supported" % a)
     tpath, tact = split_spec(target)
@@ -190,6 +251,7 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
     """-> (merged LAV text, [stderr of each rank], plan).  After the call run.last holds {"rank_seconds": [...],
     "owned_bases": [...], "split": bool} of this run."""
     check_supported(target, list(args))
+    fmt = output_format(list(args))
     qpath, qact = split_spec(query)
     index = fasta_index(qpath)
     lengths = [r[3] for r in index]
@@ -215,6 +277,8 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
         for r in range(ranks):
             e = dict(os.environ)
             e.update(env or {})
+            if fmt != "lav":
+                e["LZGPU_UNIT_MARKERS"] = "1"
             e.update({"LZGPU_RANK": str(r), "LZGPU_WORLD": str(ranks), "LZGPU_SHARE_DIR": share, "LZGPU_UNIT_PLAN": planf,
                       "LZGPU_SHARE_NONCE": nonce, "LOCAL_RANK": str(devices[r] if devices else r)})
             if transport:
@@ -238,7 +302,9 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
         if bad:
             raise RuntimeError("rank %d failed (rc %d): %s" % (bad[0], procs[bad[0]].returncode, errs[bad[0]][-2000:]))
         run.last = {"rank_seconds": secs, "owned_bases": [sum(lengths[i] for i in {qi for qi, _ in p}) for p in plan], "split": split}
-        return merge_lav(outs, [(qfiles[r], qpath) for r in range(ranks)]), errs, plan
+        rename = [(qfiles[r], qpath) for r in range(ranks)]
+        merged = merge_lav(outs, rename) if fmt == "lav" else merge_marked(outs, fmt, rename)
+        return merged, errs, plan
     finally:
         if not keep:
             shutil.rmtree(tmp, ignore_errors=True)

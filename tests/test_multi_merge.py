@@ -78,3 +78,33 @@ def test_index_of_a_fasta_and_rank_files(tmp_path):
     with pytest.raises(ValueError):
         multi.check_supported(src, [])                                           # several target sequences, no [multi]
     multi.check_supported(src + "[multi]", ["--format=lav"])
+
+
+def test_line_oriented_formats_merge_by_unit_markers():
+    """MAF / AXT / general: the bound binary prints '#lzgpu-unit <contig> <strand>' before a unit's records
+    (integration/lzgpu_shim.c::unit_marker); the launcher sorts the units and counts AXT's numbers again"""
+    head = "# lastz /tmp/x/query.rank0.fa --format=axt\n#\n"
+    rec = lambda n, q, s: "%d t 1 5 %s 1 5 %s 400\nACGTA\nACGTA\n\n" % (n, q, s)
+    r0 = head + "#lzgpu-unit 1 1\n" + rec(0, "qa", "-") + rec(1, "qa", "-") + "#lzgpu-unit 3 0\n" + rec(2, "qc", "+")
+    r1 = head.replace("rank0", "rank1") + "#lzgpu-unit 1 0\n" + rec(0, "qa", "+") + "#lzgpu-unit 2 0\n#lzgpu-unit 2 1\n" + rec(1, "qb", "-")
+    merged = multi.merge_marked([r0, r1], "axt", [("/tmp/x/query.rank0.fa", "q.fa"), ("/tmp/x/query.rank1.fa", "q.fa")])
+    want = ("# lastz q.fa --format=axt\n#\n" + rec(0, "qa", "+") + rec(1, "qa", "-") + rec(2, "qa", "-")
+            + rec(3, "qb", "-") + rec(4, "qc", "+"))
+    assert merged == want
+    # MAF keeps its records as they are
+    m0 = "##maf version=1\n#lzgpu-unit 2 0\na score=9\ns t 0 5 + 9 ACGTA\ns qb 0 5 + 7 ACGTA\n\n"
+    m1 = "##maf version=1\n#lzgpu-unit 1 0\na score=7\ns t 0 5 + 9 ACGTA\ns qa 0 5 + 7 ACGTA\n\n"
+    assert multi.merge_marked([m0, m1], "maf") == "##maf version=1\n" + m1.split("\n", 2)[2] + m0.split("\n", 2)[2]
+    # a rank that produced nothing at all contributes its header only
+    assert multi.merge_marked(["##maf version=1\n", m1], "maf") == "##maf version=1\n" + m1.split("\n", 2)[2]
+
+
+def test_formats_the_launcher_takes_and_refuses(tmp_path):
+    t = tmp_path / "t.fa"; t.write_text(">t\nACGT\n")
+    for ok in (["--format=maf"], ["--format=MAF-"], ["--axt"], ["--format=general:name1,start1,name2"], ["--format=general-"],
+               ["--format=cigar"], ["--format=sam"], ["--format=differences"], []):
+        multi.check_supported(str(t), ok)
+        assert (multi.output_format(ok) == "lav") == (ok == [])
+    for bad in (["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
+        with pytest.raises(ValueError):
+            multi.check_supported(str(t), bad)
