@@ -5,10 +5,10 @@
 // diagEnd[hashedDiag] (src/seed_search.c:1081-1126, 2612-2616, 2785-2789), so the exact
 // parallel form is 65,536 independent, order-preserving streams.  Hits are enumerated in the
 // reference's order (count -> scan -> fill gives every hit its discovery index; the table itself
-// is probed in seed-word order), scanned independently of the hash and stably partitioned by the high
-// 8 hash bits in the same pass (phase A, k_probe_part: three bases per step through an LDS look-up
-// table on 2-bit codes, lz_lut.hpp), and each partition is then dealt out to its 256 buckets inside LDS,
-// every bucket walked by one lane with diagEnd[h] in a register (phase B, k_settle).
+// is probed in seed-word order), scanned independently of the hash (phase A, k_scan_hits: four bases per
+// look-up in an LDS table on 2-bit codes, lz_lut.hpp), stably partitioned by the high 8 hash bits
+// (k_partition), and each partition is then dealt out to its 256 buckets inside LDS, every bucket walked by
+// one lane with diagEnd[h] in a register (phase B, k_settle2).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdio>
@@ -477,9 +477,10 @@ int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* tw
 // B2 step 3: the hits of a chunk, which k_fill_hits wrote in discovery order, are (a) scanned independently of
 // the diagonal hash (phase A) and (b) stably partitioned by the high 8 bits of hashedDiag into 256 streams of
 // 8-byte records (lz_lut.hpp), one stream per workgroup of phase B.  One pass over the keys for the partition
-// offsets (k_hist + two small scans), one pass that scans and scatters (k_probe_part): 8 B read + 8 B read +
-// 8 B written per hit, where a radix sort of (key, summary) pairs moved 56.
-// -DLZ_PHASE_CLOCKS: per-phase shader-clock totals of k_probe_part / k_settle (lane 0 of every workgroup adds
+// offsets (k_hist + two small scans, on the partition bytes k_fill_hits left), one that scans (k_scan_hits,
+// k_scan_tasks), one that scatters (k_partition): 8 B + 4 B read and 8 B written per hit, where a radix sort of
+// (key, summary) pairs moved 56.
+// -DLZ_PHASE_CLOCKS: per-phase shader-clock totals of the phase kernels (lane 0 of every workgroup adds
 // its s_memtime deltas to a device array the host prints at shutdown); off in the product build
 #if defined(LZ_PHASE_CLOCKS)
 __device__ unsigned long long g_phase_clk[32];
@@ -1004,194 +1005,28 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 }
 
 // ------------------------------------------------------------------------------------------
-// B2 step 4 (phase B): one workgroup of 1024 lanes per partition (256 buckets).  The partition's records arrive
-// in discovery order; a tile of 8192 of them is loaded with coalesced reads and dealt out to the buckets inside
-// LDS by all 16 waves (counting sort by the record's low hash bits: the counting atomic hands every record its
-// rank inside (wave, bucket), offsets, placement of the records themselves so that a bucket's list is contiguous),
-// then the first 256 lanes walk one bucket each with diagEnd[h] in a register (the fast path of
-// lz_settle_record): the serial part of the whole search is this short walk.  Records a wave counted in the
-// same step get their ranks from LDS atomics in no particular order: every placed record carries its index in the
-// tile and the walk checks that the indices ascend (discovery order), sorting the rest of its list when they do
-// not.  A record that needs a real extension (an HSP candidate that passed the diagEnd test) is extended by the
-// lane's whole wave (lz_coop_extend_wave), one such record at a time.
-#ifndef LZ_ST_SPLIT
-#define LZ_ST_SPLIT  1                               // workgroups per partition: each reads the whole stream and keeps its share of the buckets
-#endif
-#define LZ_ST_TPB    (1024 / LZ_ST_SPLIT)
-#define LZ_ST_WAVES  (LZ_ST_TPB / 64)
-#define LZ_ST_NB     (LZ_NBIN / LZ_ST_SPLIT)         // buckets of one workgroup
-#ifndef LZ_ST_TILE
-#define LZ_ST_TILE   4096
-#endif
-#define LZ_ST_ROUNDS (LZ_ST_TILE / LZ_ST_TPB)
 #ifndef LZ_ST_BATCH
-#define LZ_ST_BATCH  4
+#define LZ_ST_BATCH  4                               // records a walking lane settles per straight-line step
 #endif
-__global__ void __launch_bounds__(LZ_ST_TPB)
-k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__ bin_base, u32* __restrict__ diag_end,
-         const s32* __restrict__ score_tab_g, LzHspRec* __restrict__ out, u32* __restrict__ out_count, u32 out_cap,
-         u64* __restrict__ counters)
-{
-    __shared__ s32 tab[LZ_NCLASS * LZ_NCLASS];
-    __shared__ u64 rec[LZ_ST_TILE + LZ_ST_BATCH];
-    __shared__ u32 cnt[LZ_ST_WAVES][LZ_ST_NB];
-    __shared__ u32 wtot[4];
-    __shared__ u32 lbeg[LZ_ST_NB], lcnt[LZ_ST_NB];
-    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    for (int k = tid; k < LZ_NCLASS * LZ_NCLASS; k += LZ_ST_TPB) tab[k] = score_tab_g[k];
-    // The walk is bound by the latency of its short dependent steps, not by lanes: the 256 buckets are spread over
-    // all 16 waves (16 lanes each), so that every SIMD has four walking waves to interleave instead of one.
-    const u32 part = blockIdx.x / LZ_ST_SPLIT, share = blockIdx.x % LZ_ST_SPLIT;   // this workgroup: buckets [share * LZ_ST_NB, +LZ_ST_NB) of partition `part`
-    const bool walker = lane < (LZ_ST_NB / LZ_ST_WAVES);
-    const u32 bucket = lane * LZ_ST_WAVES + w;                  // of a walker lane, inside the share
-    const u32 h = part * LZ_NBIN + share * LZ_ST_NB + (bucket & (LZ_ST_NB - 1));
-    const u32 L = P.seed_len;
-    u32 dend = walker ? diag_end[h] : 0u;
-    u64 n_ext = 0, n_bp = 0;
-    const u32 r0 = bin_base[part], r1 = bin_base[part + 1];
-    // a wave owns 512 consecutive records of the tile, which it takes 64 at a time
-    u64 x[LZ_ST_ROUNDS];
-#pragma unroll
-    for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane; x[rr] = ((u64)r0 + li < (u64)r1) ? recs[(size_t)r0 + li] : 0ull; }
-    for (u32 t0 = r0; t0 < r1; t0 += LZ_ST_TILE) {
-        const u32 nt = (r1 - t0 < (u32)LZ_ST_TILE) ? r1 - t0 : (u32)LZ_ST_TILE;
-        LZ_CLK_DECL;
-        for (u32 k = tid; k < LZ_ST_WAVES * LZ_ST_NB; k += LZ_ST_TPB) (&cnt[0][0])[k] = 0;
-        __syncthreads();
-        LZ_CLK(16);
-        u32 slot[LZ_ST_ROUNDS];
-#pragma unroll
-        for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
-            const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
-            const u32 b8 = LZ_REC_LOW8(x[rr]);
-            slot[rr] = (li < nt && b8 / LZ_ST_NB == share) ? atomicAdd(&cnt[w][b8 % LZ_ST_NB], 1u) : 0xFFFFFFFFu;    // (0xFFFFFFFF: not this workgroup's)
-        }
-        __syncthreads();
-        LZ_CLK(17);
-        // offsets: bucket-major, wave order inside a bucket
-        u32 mine = 0;
-        if (tid < LZ_ST_NB) for (u32 k = 0; k < LZ_ST_WAVES; k++) { const u32 v = cnt[k][tid]; cnt[k][tid] = mine; mine += v; }
-        const u32 beg = lz_exscan256(mine, wtot);
-        if (tid < LZ_ST_NB) { for (u32 k = 0; k < LZ_ST_WAVES; k++) cnt[k][tid] += beg; lbeg[tid] = beg; lcnt[tid] = mine; }
-        __syncthreads();
-        LZ_CLK(18);
-#pragma unroll
-        for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) {
-            const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane;
-            if (slot[rr] != 0xFFFFFFFFu) rec[cnt[w][LZ_REC_LOW8(x[rr]) % LZ_ST_NB] + slot[rr]] = lz_rec_with_index(x[rr], li);
-        }
-        __syncthreads();
-        LZ_CLK(19);
-        // the next tile's records are requested before this one is walked
-        if (t0 + LZ_ST_TILE < r1) {
-#pragma unroll
-            for (int rr = 0; rr < LZ_ST_ROUNDS; rr++) { const u32 li = w * (64u * LZ_ST_ROUNDS) + (u32)rr * 64u + lane; x[rr] = ((u64)t0 + LZ_ST_TILE + li < (u64)r1) ? recs[(size_t)t0 + LZ_ST_TILE + li] : 0ull; }
-        }
-        {
-            u32 p = walker ? lbeg[bucket] : 0u; const u32 end = walker ? p + lcnt[bucket] : 0u;
-            u32 ne = 0, nb = 0, prev = 0;                       // prev: tile index + 1 of the last record taken
-            for (;;) {
-                // every lane settles records from their phase-A summaries, LZ_ST_BATCH at a time, until one needs a
-                // real extension
-                bool pending = false; u32 pp2 = 0, ppay = 0;
-                bool disorder = false;
-                while (__ballot(p < end && !pending)) {         // straight-line batches: a lane that has stopped idles through selects
-                    u64 r[LZ_ST_BATCH];
-#pragma unroll
-                    for (int k = 0; k < LZ_ST_BATCH; k++) r[k] = rec[p + k];            // (reads past `end` stay inside rec[] and are not used)
-                    bool live = !pending && !disorder;
-                    u32 np = 0;
-#pragma unroll
-                    for (int k = 0; k < LZ_ST_BATCH; k++) {
-                        const u32 ix = LZ_REC_INDEX(r[k]) + 1u, p2 = LZ_REC_POS2(r[k]), pay = LZ_REC_PAYLOAD(r[k]);
-                        const bool in = live && (p + (u32)k < end);
-                        const bool bad = ix <= prev;                               // not in discovery order
-                        const bool drop = dend > p2 - L;                           // :1113
-                        const bool slow = LZ_REC_SLOW(r[k]) != 0 && !drop;
-                        const bool go = in && !bad && !slow;                       // the record is consumed here
-                        const bool fast = go && !drop;
-                        const u32 room = p2 - dend, dlo = pay & 0xFFu, dext = pay >> 8;
-                        const u32 extent = p2 + dext;                              // :2785
-                        ne += fast ? 1u : 0u;
-                        nb += fast ? (dlo < room ? dlo : room) + dext : 0u;        // :2818
-                        dend = (fast && extent > dend) ? extent : dend;
-                        prev = go ? ix : prev; np += go ? 1u : 0u;
-                        disorder = disorder || (in && bad);
-                        if (in && !bad && slow) { pending = true; pp2 = p2; ppay = pay; }
-                        live = go;
-                    }
-                    p += np;
-                    if (disorder) {                             // the rest of the list into ascending tile order (insertion sort)
-                        for (u32 a = p + 1; a < end; a++) {
-                            const u64 v = rec[a]; const u32 iv = LZ_REC_INDEX(v);
-                            u32 q = a;
-                            while (q > p && LZ_REC_INDEX(rec[q - 1]) > iv) { rec[q] = rec[q - 1]; q--; }
-                            rec[q] = v;
-                        }
-                        disorder = false;
-                    }
-                }
-                u64 mask = __ballot(pending);
-                LZ_CLK(20);
-                if (!mask) break;
-                while (mask) {                                  // the wave extends the pending hits, one at a time
-                    const int src = (int)__ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const u32 sp2 = (u32)__shfl((int)pp2, src), spay = (u32)__shfl((int)ppay, src), sdend = (u32)__shfl((int)dend, src);
-                    const u32 sh_ = part * LZ_NBIN + share * LZ_ST_NB + (u32)src * LZ_ST_WAVES + w;
-                    const s32 diag = (s32)((spay << 16) | sh_);
-                    const u32 pos1 = sp2 + (u32)diag;
-                    s32 stopl = (s32)sdend + diag;  if (stopl < 0) stopl = 0;                                     // :2612-2616
-                    const s32 stopr = ((s32)P.tlen <= (s32)P.qlen + diag) ? (s32)P.tlen : (s32)P.qlen + diag;     // :2675-2677
-                    const LzCoopSide S = lz_coop_extend_wave(P, tab, pos1, diag, stopl, stopr, lane);
-                    const u32 l_stop = (u32)__shfl((int)S.stop_pos, 0), l_bpos = (u32)__shfl((int)S.best_pos, 0); const s32 l_best = __shfl(S.best, 0);
-                    const u32 r_stop = (u32)__shfl((int)S.stop_pos, 32), r_bpos = (u32)__shfl((int)S.best_pos, 32); const s32 r_best = __shfl(S.best, 32);
-                    if ((int)lane == src) {
-                        ne++; nb += r_stop - l_stop;                                             // :2818
-                        const u32 extent = (u32)((s32)r_stop - diag);                            // :2785
-                        if (extent > dend) dend = extent;
-                        const s32 sim = l_best + r_best;
-                        if (sim >= P.min_score) {
-                            const u32 oslot = atomicAdd(out_count, 1u);
-                            if (oslot < out_cap) { LzHspRec o; o.seed_pos1 = pos1; o.seed_pos2 = sp2; o.end1 = r_bpos; o.length = r_bpos - l_bpos; o.score = sim; out[oslot] = o; }
-                        }
-                        prev = LZ_REC_INDEX(rec[p]) + 1u;
-                        p++;
-                    }
-                    LZ_CLK(23);
-#if defined(LZ_PHASE_CLOCKS)
-                    if (threadIdx.x == 0) atomicAdd(&g_phase_clk[24], 1ull);
-#endif
-                }
-            }
-            n_ext += ne; n_bp += nb;
-            LZ_CLK(21);
-        }
-        __syncthreads();
-        LZ_CLK(22);
-    }
-    if (walker) diag_end[h] = dend;
-    for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }
-    if (lane == 0) {
-        if (n_ext) atomicAdd((unsigned long long*)&counters[0], (unsigned long long)n_ext);
-        if (n_bp)  atomicAdd((unsigned long long*)&counters[1], (unsigned long long)n_bp);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Phase B, pipelined (round 3).  Same job as k_settle, one workgroup of 1024 lanes per partition, but the 16 waves
-// have two roles and meet at ONE barrier per tile:
+// B2 phase B: one workgroup of 1024 lanes per partition (256 buckets), diagEnd of its buckets in registers.  The
+// partition's records arrive in discovery order; tiles of them are dealt out to the buckets inside LDS (counting
+// sort by the record's low hash bits, a bucket's list contiguous and in order) and every bucket's list is walked
+// by one lane (the fast path of lz_settle_record): the serial part of the whole search is this short walk.  A
+// record that needs a real extension (an HSP candidate that passed the diagEnd test) is extended by the lane's
+// whole wave (lz_coop_extend_wave), one such record at a time.  The 16 waves have two roles and meet at ONE
+// barrier per tile (round 2's kernel did count / offsets / place / walk one after the other behind five barriers,
+// 16 walking lanes in every wave):
 //   waves 0..3   walkers: lane l of wave w walks bucket 64 w + l of the tile that was placed during the previous
-//                interval -- all 64 lanes of a walking wave are busy (k_settle walked with 16 lanes of every wave:
-//                the walk was bound by VALU issue, 4 x the instructions it needs);
+//                interval -- all 64 lanes of a walking wave are busy;
 //   waves 4..15  sorters: while tile t is walked they place tile t+1 (offsets from the counts taken one interval
 //                earlier, each wave computing the 256 bucket bases for itself from the per-wave counts: no barrier
 //                between scan and placement) and count tile t+2 (ranks inside (wave, bucket)).
 // Ranks are deterministic: the lanes of a round that hold the same bucket find each other through a 64-bit
 // bitmap in LDS (atomic OR of 1 << lane, then a read: the set of peers is independent of the order in which the
 // hardware applies the ORs), rank = peers in lower lanes, and the highest peer adds the group to the wave's
-// running count.  k_settle took the rank from the return value of a same-address LDS atomic add and repaired
-// disorder after the fact; here no order is assumed anywhere.
+// running count.  (Round 2 took the rank from the return value of a same-address LDS atomic add and repaired
+// disorder after the fact, which leans on an order the ISA does not promise; here no order is assumed anywhere.)
 #define LZ_S2_TPB     1024
 #ifndef LZ_S2_WALKW
 #define LZ_S2_WALKW   4                                  // walking waves: 256 / LZ_S2_WALKW buckets each
@@ -1200,7 +1035,7 @@ k_settle(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict__
 #ifndef LZ_S2_ROUNDS
 #define LZ_S2_ROUNDS  6                                  // records per sorter lane and tile (3: 26.7, 4: 24.6, 6: 22.8 ms per step)
 #endif
-#define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 3072
+#define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 4608
 struct LzSettle2Shared {
     s32 tab[LZ_NCLASS * LZ_NCLASS];
     u64 rec[2][LZ_S2_TILE + LZ_ST_BATCH];                // the placed tiles (bucket-major), two take turns
@@ -1387,15 +1222,10 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
-    static const bool old_kernel = getenv("LZGPU_SETTLE_OLD") != nullptr;      // A/B aid: round 2's k_settle
     c.timer.begin("k_settle", s);
-    if (old_kernel)
-        hipLaunchKernelGGL(k_settle, dim3(LZ_NBIN * LZ_ST_SPLIT), dim3(LZ_ST_TPB), 0, s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
-    else {
-        static bool attr_set = false;
-        if (!attr_set) { LZ_HIP(hipFuncSetAttribute((const void*)k_settle2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzSettle2Shared))); attr_set = true; }
-        hipLaunchKernelGGL(k_settle2, dim3(LZ_NBIN), dim3(LZ_S2_TPB), sizeof(LzSettle2Shared), s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
-    }
+    static bool attr_set = false;
+    if (!attr_set) { LZ_HIP(hipFuncSetAttribute((const void*)k_settle2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzSettle2Shared))); attr_set = true; }
+    hipLaunchKernelGGL(k_settle2, dim3(LZ_NBIN), dim3(LZ_S2_TPB), sizeof(LzSettle2Shared), s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);
     c.timer.end(s);
     LZ_HIP(hipGetLastError());
     return 0;

@@ -17,8 +17,8 @@ every rank: about 1 s of host time per 50 Mbp of query, whoever owned it.)  Quer
 (2bit, hsx, files with actions other than the ones passed through) fall back to "every rank reads everything".
 
 A rank produces the stanzas of its own units only; this module puts them back in the reference's order: queries in
-file order, + strand before - strand (src/lastz.c:1592-1691).  LAV is merged by its stanzas; MAF, AXT, general, cigar,
-sam and differences by unit markers the bound binary prints (LZGPU_UNIT_MARKERS); anything else is refused before
+file order, + strand before - strand (src/lastz.c:1592-1691).  LAV is merged by its stanzas; MAF, AXT, general, cigar
+and differences by unit markers the bound binary prints (LZGPU_UNIT_MARKERS); anything else is refused before
 anything is launched.
 """
 import argparse
@@ -186,9 +186,10 @@ def output_format(args):
 
 def line_oriented(fmt):
     """formats whose output is a header followed by self-contained records, nothing at the end and no state carried from
-    one unit to the next beyond AXT's running number (src/maf.c, src/axt.c, src/genpaf.c, src/cigar.c, src/sam.c)"""
+    one unit to the next beyond AXT's running number (src/maf.c, src/axt.c, src/genpaf.c, src/cigar.c).  SAM is not
+    one of them: the reference prints an @SQ line whenever a query is loaded, before the unit's marker."""
     base = re.split(r"[:+-]", fmt.lstrip("~"), 1)[0]
-    return base in ("maf", "axt", "waxt", "general", "mapping", "cigar", "sam", "softsam", "differences")
+    return base in ("maf", "axt", "waxt", "general", "mapping", "cigar", "differences")
 
 
 def split_marked(text):
@@ -232,7 +233,7 @@ def check_supported(target, args):
     """what the merger cannot put back together is refused before any rank starts"""
     fmt = output_format(args)
     if fmt != "lav" and not line_oriented(fmt):
-        raise ValueError("lastz_amd.multi merges LAV, MAF, AXT, general, cigar, sam and differences output (got %s); run "
+        raise ValueError("lastz_amd.multi merges LAV, MAF, AXT, general, cigar and differences output (got %s); run "
                          "the formats the launcher does not know through a single lastz_gpu process" % fmt)
     for a in args:
         if a.startswith("--output=") or a == "--markend":

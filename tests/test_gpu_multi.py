@@ -105,3 +105,21 @@ def test_a_rank_parses_only_what_it_owns_at_size(tmp_path):
     print("single process %.1f s; ranks %s s for %s owned bases" % (single_s, ["%.1f" % x for x in info["rank_seconds"]], info["owned_bases"]))
     # (two ranks share ONE GPU here, so their GPU stages take turns: the wall clocks only show that nothing is worse)
     assert max(info["rank_seconds"]) < 1.2 * single_s
+
+
+@needs_bins
+@pytest.mark.parametrize("fmt", ["maf", "axt", "general:name1,zstart1,end1,name2,strand2,zstart2,end2,score,cigarx", "cigar", "differences"])
+def test_two_ranks_merge_line_oriented_formats(pair, fmt):
+    """the records of MAF / AXT / general / cigar / differences output, put back in file order by the unit markers
+    (integration/lzgpu_shim.c::unit_marker), are the single process's and the pristine reference's byte for byte"""
+    flags = ["--ydrop=9430", "--format=" + fmt]
+    t, q = str(pair / "t.fa"), str(pair / "q.fa")
+    merged, errs, plan = multi.run(t, q, flags, ranks=2, lastz=GPU_BIN, devices=[0, 0], transport="file",
+                                   env={"LZGPU_VERBOSE": "1"})
+    ref, _ = _run(REF_BIN, [t, q] + flags, pair)
+    drop = lambda s: "".join(l for l in s.splitlines(True) if not (l.startswith("#")) or l.startswith("#name"))   # header comments carry the binary's name
+    assert "#lzgpu-unit" not in merged
+    assert drop(merged) == drop(ref)
+    assert len(drop(merged).splitlines()) > 20
+    for r in (0, 1):
+        assert "[lzgpu] gapped: done on the GPU" in errs[r]

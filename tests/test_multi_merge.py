@@ -102,9 +102,9 @@ def test_line_oriented_formats_merge_by_unit_markers():
 def test_formats_the_launcher_takes_and_refuses(tmp_path):
     t = tmp_path / "t.fa"; t.write_text(">t\nACGT\n")
     for ok in (["--format=maf"], ["--format=MAF-"], ["--axt"], ["--format=general:name1,start1,name2"], ["--format=general-"],
-               ["--format=cigar"], ["--format=sam"], ["--format=differences"], []):
+               ["--format=cigar"], ["--format=differences"], []):
         multi.check_supported(str(t), ok)
         assert (multi.output_format(ok) == "lav") == (ok == [])
-    for bad in (["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
+    for bad in (["--format=sam"], ["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
         with pytest.raises(ValueError):
             multi.check_supported(str(t), bad)
