@@ -14,6 +14,7 @@
 #include <stdbool.h>
 #include <unistd.h>
 #include <time.h>
+#include <stdio_ext.h>
 #include "build_options.h"
 #include "utilities.h"
 #include "dna_utilities.h"
@@ -87,18 +88,45 @@ static void note (const char* what, const char* how)
 		}
 	}
 
+/* ---- the reference reads its sequence files one getc() at a time (seq_getc, src/sequences.c).  glibc takes the
+ * stream's lock on every such call once the process has a second thread, and the HIP runtime starts several: the
+ * 50 Mbp query of the bench pair -- read after the device came up for the table -- took 1.1 s to load against 0.35 s
+ * for the target of the same size, read before.  The reference touches its files from main()'s thread only, so
+ * every stream it opens (and standard output) is switched to caller-side locking. */
+FILE* ref_fopen_or_die (const char* name, const char* mode);
+FILE* fopen_or_die (const char* name, const char* mode)
+	{
+	FILE* f = ref_fopen_or_die (name, mode);
+	if ((f != NULL) && (getenv ("LZGPU_LOCKED_STDIO") == NULL)) __fsetlocking (f, FSETLOCKING_BYCALLER);
+	return f;
+	}
+
+__attribute__((constructor)) static void unlocked_stdout (void)
+	{
+	if (getenv ("LZGPU_LOCKED_STDIO") == NULL) __fsetlocking (stdout, FSETLOCKING_BYCALLER);
+	}
+
+/* a clock line without a note: entry points of the stages, for tools/cli_prof.sh */
+static void clock_mark (const char* what, const char* how)
+	{
+	struct timespec ts;
+	if (getenv ("LZGPU_VERBOSE_CLOCK") == NULL) return;
+	clock_gettime (CLOCK_MONOTONIC, &ts);
+	fprintf (stderr, "[lzgpu clock] %.3f s (monotonic) at %s: %s\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9, what, how);
+	}
+
 /* The HIP runtime and the device context take 0.2-0.3 s to come up; lastz spends that long parsing the target
- * file before it first needs the device.  LZGPU_EARLY_INIT=1: with two file arguments on the command line the
- * library starts its initialisation on a thread of its own while main() is still reading options
- * (lzgpu_init_async; every entry point waits for it).  OFF by default: measured on the 50 Mbp pair it LOSES 0.6 s
- * (2.91 against 2.26 s wall; the runtime's start-up work and the reference's byte-at-a-time FASTA reader get in each
- * other's way), so the overlap is left to hosts whose own start-up is not a memory-bound loop. */
+ * file before it first needs the device.  With two file arguments on the command line the library starts its
+ * initialisation on a thread of its own while main() is still reading options (lzgpu_init_async; every entry
+ * point waits for it): 1.36 against 1.49 s wall on the 50 Mbp pair.  LZGPU_EARLY_INIT=0 turns it off.  (Before the
+ * reference's streams were switched to caller-side locking, above, this LOST 0.6 s: the runtime's threads exist
+ * earlier, so the target file too was read through locked getc() calls.) */
 __attribute__((constructor)) static void early_device_start (int argc, char** argv, char** envp)
 	{
 	int k, files = 0;
 	char* e = getenv ("LZGPU_EARLY_INIT");
 	(void) envp;
-	if ((e == NULL) || (e[0] != '1')) return;
+	if ((e != NULL) && (e[0] == '0')) return;
 	for (k=1 ; k<argc ; k++)
 		{
 		if (strncmp (argv[k], "--help", 6) == 0) return;
@@ -330,6 +358,7 @@ postable* build_seed_position_table
 
 	if ((twMode != twOff) && (seq->v != devTargetV))
 		return new_position_table (hitSeed->weight, start, e, step, true, true, false);    /* (a window of the tweener: nobody reads its table) */
+	clock_mark ("table", "called");
 
 	/* the device holds ONE table: while the main target's table is live, any other table (the
 	   tweener's 7-mer tables on <=20 kbp windows when they are not batched, src/tweener.c:791) is built by the reference */
@@ -459,6 +488,7 @@ u64 seed_hit_search
 		return basesHit;
 		}
 
+	clock_mark ("search", "called");
 	/* one process per GPU: a unit of another rank yields nothing here, whichever routine would have searched it
 	 * (the tweener's windows are cut from a unit this rank owns: src/tweener.c:1073-1075 gives them no file) */
 	if (seq2->fileType != seq_type_nofile)
@@ -519,6 +549,7 @@ alignel* gapped_extend
 	alignel*       head = NULL, *last = NULL, *el;
 	int            rc;
 
+	if (twMode == twOff) clock_mark ("gapped", "called");
 	if (twMode == twReplaySearch)                               /* a window's anchors (chained by the reference): noted, extended later */
 		{
 		twWindow* w = &twWin[twCursor-1];
