@@ -190,8 +190,7 @@ int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen);
 /* ---- B3: gapped extension -----------------------------------------------------------------
  * Replaces reduce_to_points(seq1,seq2,scoring,anchors) + gapped_extend(seq1,rev1,seq2,rev2,
  * inhibitTrivial,scoring,anchors,tb,allBounds,yDrop,trimToPeak,scoreThresh,...)
- * (src/gapped_extend.c:463-559,1012-1604) for non-partitioned sequences, allBounds==0,
- * trimToPeak==1, 'S' thresholds. */
+ * (src/gapped_extend.c:463-559,1012-1604), 'S' thresholds, no limit on paired bases. */
 typedef struct lz_segment {        /* struct segment, src/segment.h:46-60                         */
     uint32_t pos1, pos2, length;
     int32_t  s;
@@ -228,6 +227,11 @@ typedef struct lz_gapped_args {
        target[t_off, t_off + t_len) x query[q_off, q_off + q_len) as its whole sequences -- anchors, sep1 / sep2
        and the alignments returned are relative to the rectangle.  t_len == 0 / q_len == 0: the whole sequence. */
     uint32_t       t_off, t_len, q_off, q_len;
+    /* gapped_extend's allBounds (--allgappedbounds, src/gapped_extend.c:1411-1429): alignments below score_thresh
+       still bound the later extensions and are dropped only from the list returned.  no_trim = !trimToPeak
+       (--noytrim, :3747-3750, :3866): an extension that reaches the end of either sequence may end there instead
+       of at its score peak.  Both 0 = lastz's defaults.                                                           */
+    int32_t        all_bounds, no_trim;
 } lz_gapped_args;
 
 typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */
@@ -283,7 +287,7 @@ int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* tot
 int lzgpu_set_hit_capacity(uint64_t max_hits_per_chunk);
 int lzgpu_set_hsp_capacity(uint64_t max_candidate_hsps);
 int lzgpu_set_dp_slot(uint32_t first_try_traceback_bytes_per_dp);
-int lzgpu_set_dp_window(uint32_t max_anchors_speculated_per_round);
+int lzgpu_set_dp_window(uint32_t max_anchors_speculated_per_round);   /* 0: the default, 1/32 of the anchors within [2048, 16384] */
 /* the one-sided DP that swept the most rows since the last reset: out = { rows, cells, shader-clock ticks of the row
  * sweep, ticks of the traceback } (a launch lasts as long as its longest DP: ticks / rows is the figure of merit of
  * k_ydrop) */

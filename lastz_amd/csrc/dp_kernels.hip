@@ -125,6 +125,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 #ifndef LZ_DP_WPE
 #define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow: six DPs of four waves per CU
 #endif
+template <bool NOTRIM>
 __global__ void __launch_bounds__(LZ_DP_LANES, LZ_DP_WPE)
 k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
         const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
@@ -142,10 +143,11 @@ k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* _
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
     const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its snapshot, its query)
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
+template <bool NOTRIM>
 __global__ void __launch_bounds__(LZ_DP_LANES)
 k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
              const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u8* __restrict__ rings)
@@ -161,7 +163,7 @@ k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJ
     const LzDpJob J = jobs[j];
     const LzDpProblem pb = problems[J.problem];
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -249,11 +251,11 @@ struct HipDpExec : LzDpExecutor {
             if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
             wide_runs += n;
             c.timer.begin("k_ydrop_wide", c.stream);
-            hipLaunchKernelGGL(k_ydrop_wide, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+            hipLaunchKernelGGL(P.no_trim ? k_ydrop_wide<true> : k_ydrop_wide<false>, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.timer.begin("k_ydrop", c.stream);
-            hipLaunchKernelGGL(k_ydrop, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
+            hipLaunchKernelGGL(P.no_trim ? k_ydrop<true> : k_ydrop<false>, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
         c.timer.end(c.stream);
@@ -424,8 +426,11 @@ struct HipDpExec : LzDpExecutor {
 
 static u32 g_dp_slot_tb = 8u << 20;
 extern "C" int lzgpu_set_dp_slot(uint32_t bytes) { if (bytes < 65536) return LZGPU_ERR_ARG; g_dp_slot_tb = bytes; return 0; }
-static u32 g_dp_window = 2048;       // anchors speculated per round (a 50 Mbp strand has ~1150 that need a DP: one full launch instead of two)
-extern "C" int lzgpu_set_dp_window(uint32_t n) { if (n < 1) return LZGPU_ERR_ARG; g_dp_window = n; return 0; }
+// Anchors speculated per round.  A launch lasts as long as its longest DP, so the fewer rounds the better: 2048 holds
+// the ~1150 anchors of a 50 Mbp strand that need a DP in one launch; a 200 Mbp strand has ~4500 (north star:
+// 7 launches, 0.73 s at 2048; 5 launches, 0.48 s at 8192 and beyond).  Default: 1/32 of the anchors, within [2048, 16384].
+static u32 g_dp_window = 0;          // 0: the default rule; lzgpu_set_dp_window / LZGPU_DP_WINDOW fix it
+extern "C" int lzgpu_set_dp_window(uint32_t n) { g_dp_window = n; return 0; }
 
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len);     // lzgpu_api.hip
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256]);
@@ -505,9 +510,10 @@ int gapped_prepare(LzCtx& c, const lz_gapped_args* a, int temp_slot, const u8 ro
     LzGappedParams& G = gp.G;
     G.t = c.target.host.data() + a->t_off; G.tlen = gp.tlen; G.q = qhost + a->q_off; G.qlen = gp.qlen; G.sub = a->sub;
     G.gap_open = a->gap_open; G.gap_extend = a->gap_extend; G.ydrop = a->ydrop; G.score_thresh = a->score_thresh;
-    G.window = g_dp_window;
+    G.window = g_dp_window ? g_dp_window : std::min<u32>(16384u, std::max<u32>(2048u, a->n_anchors / 32u));
     G.sep1 = a->sep1; G.n_sep1 = a->sep1 ? a->n_sep1 : 0; G.sep2 = a->sep2; G.n_sep2 = a->sep2 ? a->n_sep2 : 0;
     G.strands_differ = a->strands_differ != 0; G.inhibit_trivial = a->inhibit_trivial != 0;
+    G.all_bounds = a->all_bounds != 0;
     if ((a->sep1 && a->n_sep1 < 2) || (a->sep2 && a->n_sep2 < 2)) return lz_fail(LZGPU_ERR_ARG, "a partitioned sequence needs at least two separators");
     if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
     return 0;
@@ -537,6 +543,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     for (u32 k = 1; k < n; k++) {
         const lz_gapped_args& a = args[k];
         if (!a.sub || a.gap_open != a0.gap_open || a.gap_extend != a0.gap_extend || a.ydrop != a0.ydrop || a.traceback_bytes != a0.traceback_bytes
+            || (a.no_trim != 0) != (a0.no_trim != 0)
             || (a.sub != a0.sub && memcmp(a.sub, a0.sub, 65536 * sizeof(int32_t)) != 0))
             return lz_fail(LZGPU_ERR_ARG, "lzgpu_gapped_extend_batch: the problems of a batch must share the scoring");
     }
@@ -556,6 +563,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     ex.P.tdp = gp[0].tdp; ex.P.tlen = gp[0].tlen; ex.P.qdp = gp[0].qdp; ex.P.qlen = gp[0].qlen;
     ex.P.gap_e = a0.gap_extend; ex.P.gap_oe = a0.gap_open + a0.gap_extend; ex.P.ydrop = a0.ydrop;
     ex.P.ydrop_tail = a0.ydrop / a0.gap_extend + 6;                      // :3484-3492
+    ex.P.no_trim = a0.no_trim != 0;
     ex.P.tb_len = a0.traceback_bytes ? a0.traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
     ex.slot_tb = g_dp_slot_tb;
     { u32 nr = 0; for (int b = 0; b < 256; b++) if (rowc[b] >= nr) nr = (u32)rowc[b] + 1; ex.tab_rows = nr; }

@@ -49,7 +49,7 @@
 #define LZ_DP_STAMP_PERIOD 65535        // rows after which the 16-bit mask stamps of the LDS ring start over (tests: a small period)
 #endif
 #define LZ_DP_ACT_LDS 16              // active segments kept in LDS (the rest in the job's HBM slot: LDS bytes per DP decide how many DPs share a CU)
-#define LZ_DP_MAXACT  320             // active segments of earlier alignments crossing the sweep row
+#define LZ_DP_MAXACT  4096            // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
 enum { LZ_DIAG_SEG = 0, LZ_HORZ_SEG = 1, LZ_VERT_SEG = 2 };
@@ -99,6 +99,7 @@ struct LzDpParams {                     // per batch
     const u8* tdp; u32 tlen;            // DP-class codes of the target / query (unmasked scoring classes)
     const u8* qdp; u32 qlen;
     s32 gap_e, gap_oe, ydrop, ydrop_tail;
+    s32 no_trim;                        // !trimToPeak: an end on the last row / column may be reported instead of the peak (:3747-3750, :3866)
     u32 tb_len;                         // the REFERENCE's traceback size (truncation rule, :3640-3661)
     u8* tb_arena; u32* row_arena; u32* ops_arena;
     struct LzDpActive* act_arena;
@@ -174,6 +175,7 @@ struct LzDpLane {                       // per-lane values carried between the s
     s32 A, K; u32 cut; s32 i_in;        // walk-1 summary f(x) = cut ? A : max(A, x-K), and the scanned input
     s32 cand; u32 cand_col; s32 run_in; // best diagonal-won cell of the block; running best entering the block
     u32 first, last;                    // first / last live column of the block (0xFFFFFFFF: none)
+    s32 bnd; u32 bnd_row, bnd_col, bnd_has;   // no_trim: the lane's best diagonal-won live cell on row M / column N, the latest on ties
 };
 // Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
 // test harness); their semantics are fixed here:
@@ -367,7 +369,9 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, SH& sh, LzDpCtl& c, 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class X, class SH>
+// NOTRIM: !trimToPeak, a compile-time switch (its four per-lane values cost the default kernel nine spilled registers
+// when it was a run-time flag)
+template <bool NOTRIM, class X, class SH>
 LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
 {
@@ -436,6 +440,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     // ---- rows 1..M (:3607-3828).  One iteration = the row-end step of the row the previous iteration
     // swept, fused with the set-up of the next row (both are lane-0 work: one barrier instead of three),
     // then the three walks, separated only by the barrier inside each cross-lane step.
+    if (NOTRIM) x.step([&](int, LzDpLane& r) { r.bnd = 0; r.bnd_row = r.bnd_col = 0; r.bnd_has = 0; });
     u32 row = 0, LY0 = 0, RYi = 0, cpl = 0, trow_cur = 0; s32 best0 = 0, i_last = 0;     // of the row in flight (uniform)
     bool swept = false;
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
@@ -652,6 +657,10 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                             if (first == 0xFFFFFFFFu) first = col;
                             last = col;
                             if ((link & 3u) == LZ_C_FROM_C && c > rb) rb = c;
+                            // boundaryScore (:3747-3750) never feeds back into the sweep: every lane keeps its own
+                            // maximum (>=: the later cell wins a tie) and the lanes are compared once, after the last row
+                            if (NOTRIM && (link & 3u) == LZ_C_FROM_C && (row == M || col == N) && (!r.bnd_has || c >= r.bnd))
+                                { r.bnd = c; r.bnd_row = row; r.bnd_col = col; r.bnd_has = 1; }
                             tbr[k] = (u8)link;
                         } else {
                             sh.cc[LZ_RING(col)] = LZ_DP_NEGINF; sh.dd[LZ_RING(col)] = LZ_DP_NEGINF;
@@ -674,6 +683,26 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     // path stays on that diagonal and asks for a new window after a gap.  Edit ops are run-length merged
     // in registers (edit_script_add, src/edit_script.c:261-300) and stored once per run.
     const u64 t1 = LZ_CLOCK();
+    if (NOTRIM) {
+        // endIsBoundary (:3744, :3750, :3866): bestScore's last update is the LAST cell attaining the maximum, (end1, end2);
+        // boundaryScore's last update is the last boundary cell attaining the boundary maximum; whichever of the two
+        // events came later in row-major order stands (the same cell: the boundary, it is tested second)
+        x.phase([&](int lane, LzDpLane& r) {                    // (the sweep row is dead: its first cells carry the lanes' values)
+            sh.cc[lane] = r.bnd_has ? r.bnd : LZ_DP_NEGINF - (1 << 24);
+            sh.cc[LZ_DP_LANES + lane] = (s32)r.bnd_row; sh.cc[2 * LZ_DP_LANES + lane] = (s32)r.bnd_col;
+            sh.dd[lane] = (s32)r.bnd_has;
+        });
+        x.phase([&](int lane, LzDpLane&) {
+            if (lane != x.lead_lane() || ct.status != LZ_DP_OK) return;
+            bool has = false; s32 bc = 0; u32 br = 0, bcol = 0;
+            for (int l = 0; l < LZ_DP_LANES; l++) {
+                if (!sh.dd[l]) continue;
+                const s32 c = sh.cc[l]; const u32 rr = (u32)sh.cc[LZ_DP_LANES + l], cl = (u32)sh.cc[2 * LZ_DP_LANES + l];
+                if (!has || c > bc || (c == bc && (rr > br || (rr == br && cl > bcol)))) { has = true; bc = c; br = rr; bcol = cl; }
+            }
+            if (has && (br > ct.end1 || (br == ct.end1 && bcol >= ct.end2))) { ct.best = bc; ct.end1 = br; ct.end2 = bcol; }
+        });
+    }
     x.phase([&](int lane, LzDpLane&) {
         if (lane != x.lead_lane()) return;
         sh.tb_row = ct.end1; sh.tb_col = ct.end2; sh.tb_prev = 0; sh.tb_nops = 0; sh.tb_run_op = 0; sh.tb_run_len = 0;

@@ -550,7 +550,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             std::vector<LzDpSeg> segs;
             format_segments(b, segs);
             if (segs.empty()) continue;                        // empty alignment, :1401-1405
-            if (b.s < G.score_thresh) continue;                // :1419-1429 (allBounds == false)
+            if (!G.all_bounds && b.s < G.score_thresh) continue;     // :1419-1429
             LzDpAlign m; memset(&m, 0, sizeof(m));
             m.pos1 = b.start1; m.pos2 = b.start2; m.end1 = b.stop1; m.end2 = b.stop2;
             m.first_seg = (s32)S.segs.size(); m.last_seg = m.first_seg + (s32)segs.size() - 1;

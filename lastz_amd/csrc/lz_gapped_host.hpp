@@ -45,6 +45,7 @@ struct LzGappedParams {
     const u32* sep1 = nullptr; u32 n_sep1 = 0;   // partition separators (lz_gapped_args), or none
     const u32* sep2 = nullptr; u32 n_sep2 = 0;
     bool strands_differ = false, inhibit_trivial = false;
+    bool all_bounds = false;               // low-scoring alignments bound later extensions too (:1411-1429)
 };
 
 struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };

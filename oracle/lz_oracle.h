@@ -135,6 +135,13 @@ int lzo_gapped_extend(const uint8_t* t, uint32_t tlen, const uint8_t* q, uint32_
                       uint32_t tb_size,
                       lzo_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops,
                       lzo_gapped_stats* stats);
+int lzo_gapped_extend_opts(const uint8_t* t, uint32_t tlen, const uint8_t* q, uint32_t qlen,
+                           const int32_t* sub, int32_t gap_open, int32_t gap_extend,
+                           lzo_segment* anchors, uint32_t n_anchors,
+                           int32_t ydrop, int trim_to_peak, int all_bounds, int32_t score_thresh,
+                           uint32_t tb_size,
+                           lzo_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops,
+                           lzo_gapped_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -669,6 +669,19 @@ int lzo_gapped_extend(const uint8_t* t, uint32_t tlen, const uint8_t* q, uint32_
                       lzo_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops,
                       lzo_gapped_stats* stats)
 {
+    return lzo_gapped_extend_opts(t, tlen, q, qlen, sub, gap_open, gap_extend, anchors, n_anchors, ydrop, trim_to_peak,
+                                  /* all_bounds */ 0, score_thresh, tb_size, out, n_out, ops, n_ops, stats);
+}
+
+/* all_bounds: gapped_extend's allBounds (--allgappedbounds, src/gapped_extend.c:1411-1429): an alignment below the
+ * score threshold still bounds the later extensions and is dropped only when the list is written (:1475-1566) */
+int lzo_gapped_extend_opts(const uint8_t* t, uint32_t tlen, const uint8_t* q, uint32_t qlen,
+                           const int32_t* sub, int32_t gap_open, int32_t gap_extend,
+                           lzo_segment* anchors, uint32_t n_anchors,
+                           int32_t ydrop, int trim_to_peak, int all_bounds, int32_t score_thresh, uint32_t tb_size,
+                           lzo_align** out, uint64_t* n_out, uint32_t** ops, uint64_t* n_ops,
+                           lzo_gapped_stats* stats)
+{
     lzo_gapped_stats st; memset(&st, 0, sizeof(st));
     *out = NULL; *n_out = 0; *ops = NULL; *n_ops = 0;
     if (tlen == qlen && memcmp(t, q, tlen) == 0) return 1;   /* identical sequences: trivial
@@ -707,7 +720,7 @@ int lzo_gapped_extend(const uint8_t* t, uint32_t tlen, const uint8_t* q, uint32_
         if (mp->first == NULL) { es_free(mp->script); mp->script = NULL; mp->have_align = 0; continue; }
         mp->last = mp->first->prev;
         mp->first->prev = mp->last->next = NULL;
-        if (mp->s < score_thresh) {                                           /* :1419-1429 (allBounds=false) */
+        if (!all_bounds && mp->s < score_thresh) {                            /* :1419-1429 */
             es_free(mp->script); mp->script = NULL; mp->have_align = 0; free_segs(mp); continue;
         }
         align_left_right(obi, mp);

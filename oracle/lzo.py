@@ -85,6 +85,12 @@ def lib():
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
                                     C.POINTER(GappedStats)]
+    L.lzo_gapped_extend_opts.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32,
+                                         C.c_int, C.c_int, C.c_int32, C.c_uint32,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                         C.POINTER(GappedStats)]
     _LIB = L
     return L
 
@@ -191,15 +197,15 @@ def reduce_to_points(t, q, sub, segs):
 
 
 def gapped_extend(t, q, sub, anchors, gap_open=400, gap_extend=30, ydrop=9400, trim_to_peak=True,
-                  score_thresh=3000, tb_size=0):
+                  score_thresh=3000, tb_size=0, all_bounds=False):
     """anchors: SEG_DTYPE array already reduced to points.  Returns (aligns, ops, stats)."""
     ta, qa = nul_terminated(t), nul_terminated(q)
     anchors = anchors.copy()
     out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
     st = GappedStats()
-    rc = lib().lzo_gapped_extend(_ptr(ta), len(ta) - 1, _ptr(qa), len(qa) - 1, _ptr(sub),
+    rc = lib().lzo_gapped_extend_opts(_ptr(ta), len(ta) - 1, _ptr(qa), len(qa) - 1, _ptr(sub),
                                  gap_open, gap_extend, _ptr(anchors), len(anchors), ydrop,
-                                 int(trim_to_peak), score_thresh, tb_size,
+                                 int(trim_to_peak), int(all_bounds), score_thresh, tb_size,
                                  C.byref(out), C.byref(n), C.byref(ops), C.byref(nops), C.byref(st))
     if rc != 0:
         raise RuntimeError(f"lzo_gapped_extend rc={rc}")

@@ -37,7 +37,7 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
 struct EmulExec : LzDpExecutor {
     std::vector<u8> tdp, qdp;           // padded DP-class codes
     u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
-    s32 gap_e, gap_oe, ydrop; u32 tb_len;
+    s32 gap_e, gap_oe, ydrop; u32 tb_len; s32 no_trim = 0;
     u32 tb_slot;                        // first-try slot size (tests shrink it to exercise the retry)
     u64 retries = 0, wide_runs = 0;
     int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
@@ -51,19 +51,19 @@ struct EmulExec : LzDpExecutor {
             for (;;) {
                 std::vector<u8> tb(slot); std::vector<u32> rows(slot / 16 + 16), opbuf(slot / 4 + 16);
                 LzDpParams P; P.tdp = tdp.data() + LZ_SEQ_PAD; P.tlen = tlen; P.qdp = qdp.data() + LZ_SEQ_PAD; P.qlen = qlen;
-                P.gap_e = gap_e; P.gap_oe = gap_oe; P.ydrop = ydrop; P.ydrop_tail = ydrop / gap_e + 6; P.tb_len = tb_len;
+                P.gap_e = gap_e; P.gap_oe = gap_oe; P.ydrop = ydrop; P.ydrop_tail = ydrop / gap_e + 6; P.tb_len = tb_len; P.no_trim = no_trim;
                 std::vector<LzDpActive> spill(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
                 P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data(); P.act_arena = spill.data();
                 LzDpJob& J = jobs[k];
                 J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size(); J.act_off = 0;
                 CpuPhases x;
-                lz_dp_run(x, sh, S, P, J, tab, &res[k]);
+                if (no_trim) lz_dp_run<true>(x, sh, S, P, J, tab, &res[k]); else lz_dp_run<false>(x, sh, S, P, J, tab, &res[k]);
                 if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
                     static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
                     static LzDpSharedWide shw;
                     shw.bind(ring.data());
                     CpuPhases xw;
-                    lz_dp_run(xw, shw, S, P, J, tab, &res[k]);
+                    if (no_trim) lz_dp_run<true>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false>(xw, shw, S, P, J, tab, &res[k]);
                     wide_runs++;
                 }
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
@@ -90,19 +90,23 @@ static LzGappedStats g_stats; static u64 g_retries, g_wide;
 extern "C" void emul_gapped_stats(u64* out) { out[0] = g_stats.anchors; out[1] = g_stats.anchors_extended; out[2] = g_stats.dp_runs;
     out[3] = g_stats.dp_cells; out[4] = g_stats.rounds; out[5] = g_stats.reruns; out[6] = g_retries; out[7] = g_wide; }
 
+static int g_all_bounds = 0, g_no_trim = 0;
+extern "C" void emul_gapped_options(int all_bounds, int no_trim) { g_all_bounds = all_bounds; g_no_trim = no_trim; }   // of the calls that follow
+
 extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, const s32* sub,
                                   s32 gap_open, s32 gap_extend, s32 ydrop, s32 score_thresh, u32 tb_len,
                                   lz_segment* anchors, u32 n_anchors, int reduce, u32 window, u32 tb_slot,
                                   lz_align** out, u64* n_out, u32** ops, u64* n_ops)
 {
     EmulExec ex;
+    ex.no_trim = g_no_trim;
     u8 rowc[256], colc[256];
     int rc = lzh_score_classes(sub, rowc, colc, ex.tab); if (rc) return rc;
     dp_codes(t, tlen, rowc, ex.tdp); dp_codes(q, qlen, colc, ex.qdp);
     ex.tlen = tlen; ex.qlen = qlen; ex.gap_e = gap_extend; ex.gap_oe = gap_open + gap_extend; ex.ydrop = ydrop;
     ex.tb_len = tb_len ? tb_len : 80u * 1024 * 1024; ex.tb_slot = tb_slot ? tb_slot : (1u << 22);
     LzGappedParams G; G.t = t; G.tlen = tlen; G.q = q; G.qlen = qlen; G.sub = sub;
-    G.gap_open = gap_open; G.gap_extend = gap_extend; G.ydrop = ydrop; G.score_thresh = score_thresh; G.window = window;
+    G.gap_open = gap_open; G.gap_extend = gap_extend; G.ydrop = ydrop; G.score_thresh = score_thresh; G.window = window; G.all_bounds = g_all_bounds != 0;
     if (reduce) lzh_reduce_to_points(t, q, sub, anchors, n_anchors);
     std::vector<lz_align> al; std::vector<u32> op;
     rc = lzh_gapped_extend(G, ex, anchors, n_anchors, al, op, g_stats);

@@ -12,6 +12,7 @@ Files produced here, per case <name>:
                     name2 start1(1-based) end1 start2 end2 strand2 score
   <name>.lav        default gapped run (both strands)
   <name>.stats.json collect_stats counters W,H,E,X,C (oracle/_ref/lastz_stats --stats)
+With --options: options_<opt>_<pair>.lav, the --noytrim / --allgappedbounds runs (see options()).
 """
 import json
 import os
@@ -89,5 +90,20 @@ def main():
         print(name, len(hsp.split(b"\n")) - 1, "HSPs;", lav.count("a {"), "gapped blocks")
 
 
+def options():
+    """--noytrim / --allgappedbounds runs of the pristine binary on the pairs of tests/test_oracle_vs_reference.py::
+    _option_pairs (inputs are rebuilt from the committed cases / seeds there): options_<opt>_<pair>.lav"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_oracle_vs_reference as T
+    for opt, (flags, _) in T.OPTION_CASES.items():
+        for name, (t, q) in T._option_pairs().items():
+            with tempfile.TemporaryDirectory() as d:
+                tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
+                seqio.write_fasta(tf, [("target", t)]); seqio.write_fasta(qf, [("query", q)])
+                lav = subprocess.check_output([REF, tf, qf] + flags).decode().replace(d + "/", "")
+                open(os.path.join(HERE, "options_%s_%s.lav" % (opt, name)), "w").write(lav)
+                print(opt, name, lav.count("a {"), "gapped blocks")
+
+
 if __name__ == "__main__":
-    main()
+    options() if "--options" in sys.argv else main()

@@ -27,7 +27,9 @@ def L():
     return lib
 
 
-def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3000, tb_len=0, gap_open=400, gap_extend=30):
+def emul_gapped(L, t, q, sub, segs, window=1024, tb_slot=0, ydrop=9400, thresh=3000, tb_len=0, gap_open=400, gap_extend=30,
+                all_bounds=False, no_trim=False):
+    L.emul_gapped_options(int(all_bounds), int(no_trim))
     t = np.ascontiguousarray(np.append(t, 0).astype(np.uint8)); q = np.ascontiguousarray(np.append(q, 0).astype(np.uint8))
     segs = np.ascontiguousarray(segs.copy())
     out = C.c_void_p(); n = C.c_uint64(); ops = C.c_void_p(); nops = C.c_uint64()
@@ -52,7 +54,9 @@ def _check(L, t, q, **kw):
         hsps, _ = lzo.seed_hit_search(tab, qq, masked)
         segs = lzo.hsps_to_segments(hsps, rev)
         oal, oops, ost = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), ydrop=kw.get("ydrop", 9400),
-                                           tb_size=kw.get("tb_len", 0), gap_open=kw.get("gap_open", 400), gap_extend=kw.get("gap_extend", 30))
+                                           tb_size=kw.get("tb_len", 0), gap_open=kw.get("gap_open", 400), gap_extend=kw.get("gap_extend", 30),
+                                           score_thresh=kw.get("thresh", 3000), all_bounds=kw.get("all_bounds", False),
+                                           trim_to_peak=not kw.get("no_trim", False))
         eal, eops, est = emul_gapped(L, t, qq, sub, segs.view(lzgpu.SEG_DTYPE), **kw)
         assert len(oal) == len(eal) and (oal == eal).all() and (oops == eops).all()
         assert est["dp_cells"] == ost["dp_cells"] and est["anchors_extended"] == ost["anchors_extended"]
@@ -143,3 +147,17 @@ def test_sixteen_bit_mask_stamps_start_over(L):
     assert tot["anchors_extended"] > 5
     t, q = H.load_case("adversarial")
     _check(lib, t[:30000], q[:30000])
+
+
+@pytest.mark.parametrize("kw", [dict(no_trim=True), dict(all_bounds=True, thresh=9000), dict(all_bounds=True, no_trim=True, thresh=6000)],
+                         ids=["noytrim", "allgappedbounds", "both"])
+def test_untrimmed_ends_and_all_bounds(L, kw):
+    """--noytrim (an extension that reaches the end of a sequence may end there, src/gapped_extend.c:3747-3750, :3866)
+    and --allgappedbounds (alignments below the threshold still bound later ones, :1411-1429) against the oracle: short
+    sequences whose homology runs into both ends, and the tandem-repeat obstacle course"""
+    t, q = H.load_case("adversarial")
+    _check(L, t[9000:14500], q[29500:34000], **kw)
+    t2, q2 = seqio.synth_pair(5000, 4200, seed=77, block_min=900, block_max=2500, homolog_frac=0.95)
+    for lo, hi in ((0, 4200), (300, 3300), (1200, 2600)):          # windows of the query: ends inside homologous blocks
+        _check(L, t2, q2[lo:hi], **kw)
+        _check(L, t2[lo:hi], q2, **kw)

@@ -60,7 +60,7 @@ def test_window_and_slot_invariance(gpu):
             mine, _ = _gpu_blocks(gpu, t, [q])
             assert mine == gold
     finally:
-        gpu.set_dp_window(1024); gpu.set_dp_slot(8 << 20)
+        gpu.set_dp_window(0); gpu.set_dp_slot(8 << 20)
 
 
 def test_thresholds_ydrop_truncation_vs_oracle(gpu):
@@ -211,3 +211,16 @@ def test_rectangle_of_the_sequences_as_a_problem(gpu):
         assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
     for (al, ops), (oal, oops) in zip(gpu.gapped_extend_batch(sub, problems), want):    # ... and as one batch
         assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all()
+
+
+@pytest.mark.parametrize("opt", ["noytrim", "allgappedbounds", "both"])
+def test_untrimmed_ends_and_all_bounds(gpu, opt):
+    """--noytrim (k_ydrop<true>: an extension that reaches the end of a sequence may end there,
+    src/gapped_extend.c:3747-3750, :3866) and --allgappedbounds (alignments below the threshold still bound later ones,
+    :1411-1429) against LAVs of the pristine binary (tests/golden/options_*.lav) -- no longer declined"""
+    import test_oracle_vs_reference as T
+    _, okw = T.OPTION_CASES[opt]
+    kw = dict(no_trim=not okw.get("trim_to_peak", True), all_bounds=okw.get("all_bounds", False), score_thresh=okw.get("score_thresh", 3000))
+    for name, (t, q) in T._option_pairs().items():
+        mine, _ = _gpu_blocks(gpu, t, [q], **kw)
+        assert mine == H.lav_blocks(os.path.join(H.GOLDEN, f"options_{opt}_{name}.lav")), (opt, name)

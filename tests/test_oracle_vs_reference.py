@@ -149,3 +149,52 @@ def test_live_reference_hsps(tmp_path, seed, pattern, wt, step):
         hsps, _ = lzo.seed_hit_search(tab, qq, masked)
         rows += H.hsps_as_tsv_rows("query", strand, hsps)
     assert rows == gold
+
+
+OPTION_CASES = {"noytrim": (["--noytrim"], dict(trim_to_peak=False)),
+                "allgappedbounds": (["--allgappedbounds", "--gappedthresh=9000"], dict(all_bounds=True, score_thresh=9000)),
+                "both": (["--noytrim", "--allgappedbounds", "--gappedthresh=6000"], dict(trim_to_peak=False, all_bounds=True, score_thresh=6000))}
+
+
+def _option_pairs():
+    """short pairs whose homology runs into the ends of the sequences, and the tandem-repeat obstacle course"""
+    t, q = H.load_case("adversarial")
+    t2, q2 = seqio.synth_pair(5000, 4200, seed=77, block_min=900, block_max=2500, homolog_frac=0.95)
+    return {"adversarial_piece": (t[9000:14500], q[29500:34000]), "ends_q": (t2, q2[1200:2600]), "ends_t": (t2[300:3300], q2)}
+
+
+def _oracle_blocks_with(t, q, **kw):
+    sub, masked = H.scoring()
+    tab = lzo.Table(t, lzo.seed())
+    out = []
+    for _, rev, qq in H.strands(q):
+        hsps, _ = lzo.seed_hit_search(tab, qq, masked)
+        al, ops, _ = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, lzo.hsps_to_segments(hsps, rev)), **kw)
+        if len(al):
+            out.append((1, rev, H.blocks_of(al, ops)))
+    return out
+
+
+@pytest.mark.parametrize("opt", list(OPTION_CASES))
+def test_untrimmed_ends_and_all_bounds_vs_reference_output(opt):
+    """--noytrim / --allgappedbounds of the oracle against LAVs the pristine binary wrote (tests/golden/options_*.lav,
+    made by tests/golden/make_golden.py --options) -- and, where oracle/_ref/lastz is present, against a fresh run"""
+    flags, kw = OPTION_CASES[opt]
+    changed = False
+    for name, (t, q) in _option_pairs().items():
+        mine = _oracle_blocks_with(t, q, **kw)
+        assert mine == H.lav_blocks(os.path.join(G, f"options_{opt}_{name}.lav")), (opt, name)
+        changed = changed or mine != _oracle_blocks_with(t, q, score_thresh=kw.get("score_thresh", 3000))
+    assert changed                                            # the option decides something on these inputs
+
+
+@pytest.mark.skipif(lzo.ref_binary() is None, reason="oracle/_ref/lastz not built")
+@pytest.mark.parametrize("opt", list(OPTION_CASES))
+def test_live_reference_untrimmed_ends_and_all_bounds(tmp_path, opt):
+    flags, kw = OPTION_CASES[opt]
+    for name, (t, q) in _option_pairs().items():
+        tf, qf = str(tmp_path / "t.fa"), str(tmp_path / "q.fa")
+        seqio.write_fasta(tf, [("target", t)]); seqio.write_fasta(qf, [("query", q)])
+        lav = tmp_path / "o.lav"
+        lav.write_text(H.ref_run([tf, qf] + flags))
+        assert _oracle_blocks_with(t, q, **kw) == H.lav_blocks(str(lav)), (opt, name)
