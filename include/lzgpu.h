@@ -50,6 +50,7 @@ extern "C" {
 #define LZGPU_NH_SIZE          5   /* sequence >= 2^31 bases                                        */
 #define LZGPU_NH_IDENTICAL     6   /* identical sequences (trivial self-alignment path)            */
 #define LZGPU_NH_UNSUPPORTED   7   /* option outside the fast-path predicate  */
+#define LZGPU_NH_PAIRED_LIMIT  8   /* the alignments pair more bases than max_paired_bases allows   */
 
 /* Output of the reference's seed parser (struct seed, src/seeds.h:37-76) for a strict seed:
  * packed = OR_i ((w >> shift[i]) & mask[i]) (apply_seed, src/seeds.c:1335-1378), plus the XOR
@@ -232,6 +233,11 @@ typedef struct lz_gapped_args {
        (--noytrim, :3747-3750, :3866): an extension that reaches the end of either sequence may end there instead
        of at its score peak.  Both 0 = lastz's defaults.                                                           */
     int32_t        all_bounds, no_trim;
+    /* gapped_extend's maxPairedBases (--querydepth, src/gapped_extend.c:1441-1459; 0 = no limit): the paired bases of
+       the alignments are added up as they are found; a run that stays below the limit is the run without a limit.
+       The moment the limit is exceeded the call returns LZGPU_NH_PAIRED_LIMIT with nothing produced: the reference's
+       routine then repeats the stage, warns and keeps / discards what it has as --querydepth asks.                */
+    uint64_t       max_paired_bases;
 } lz_gapped_args;
 
 typedef struct lz_align {          /* struct alignel, src/edit_script.h:30-46                     */

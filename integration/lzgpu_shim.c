@@ -589,7 +589,7 @@ alignel* gapped_extend
 		}
 
 	if ((devTargetV == NULL) || (seq1->v != devTargetV) || (seq1->len != devTargetLen)
-	 || (scoreThresh.t != 'S') || (maxPairedBases != 0)
+	 || (scoreThresh.t != 'S')
 	 || ((gapped_extend_dbgAllowBatches) && (seq1->partition.p != NULL)) || (seq2->choresFile != NULL)
 	 || (tb == NULL) || (anchors == NULL) || (anchors->len == 0) || (scoring->gapExtend <= 0))
 		{ note ("gapped", "reference path");
@@ -613,6 +613,7 @@ alignel* gapped_extend
 
 	a.strands_differ = (seq1->revCompFlags != seq2->revCompFlags);  a.inhibit_trivial = (inhibitTrivial != 0);
 	a.all_bounds = (allBounds != 0);  a.no_trim = (!trimToPeak);
+	a.max_paired_bases = maxPairedBases;                       /* (over the limit: declined, the reference's routine warns and truncates) */
 	sep1 = partition_separators (seq1, &a.n_sep1);  a.sep1 = sep1;
 	sep2 = partition_separators (seq2, &a.n_sep2);  a.sep2 = sep2;
 

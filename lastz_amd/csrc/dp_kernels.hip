@@ -513,7 +513,7 @@ int gapped_prepare(LzCtx& c, const lz_gapped_args* a, int temp_slot, const u8 ro
     G.window = g_dp_window ? g_dp_window : std::min<u32>(16384u, std::max<u32>(2048u, a->n_anchors / 32u));
     G.sep1 = a->sep1; G.n_sep1 = a->sep1 ? a->n_sep1 : 0; G.sep2 = a->sep2; G.n_sep2 = a->sep2 ? a->n_sep2 : 0;
     G.strands_differ = a->strands_differ != 0; G.inhibit_trivial = a->inhibit_trivial != 0;
-    G.all_bounds = a->all_bounds != 0;
+    G.all_bounds = a->all_bounds != 0; G.max_paired_bases = a->max_paired_bases;
     if ((a->sep1 && a->n_sep1 < 2) || (a->sep2 && a->n_sep2 < 2)) return lz_fail(LZGPU_ERR_ARG, "a partitioned sequence needs at least two separators");
     if (const char* w = getenv("LZGPU_DP_WINDOW")) { const int v = atoi(w); if (v > 0) G.window = (u32)v; }
     return 0;

@@ -377,6 +377,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     }
 
     const u32 W = G.window ? G.window : 1024;
+    u64 paired_bases = 0;
     // Which anchors of a window are worth a speculative DP.  Most anchors lie on the alignment an
     // earlier (better) anchor is about to produce -- the reference drops them in msp_left_right
     // without running a DP (98.5 % on the 10 Mbp pair).  An anchor within
@@ -562,6 +563,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             info.push_back(std::move(in));
             insert_align(S, (s32)S.aligns.size() - 1);
             if (entries[e].near_slot < slot_align.size()) slot_align[entries[e].near_slot] = (s32)S.aligns.size() - 1;
+            if (G.max_paired_bases) {                          // count_paired_bases, :5695-5706; the limit test of :1441-1459
+                for (const LzDpSeg& g : segs) if (g.type == LZ_DIAG_SEG) paired_bases += (u64)g.e1 + 1 - g.b1;
+                if (paired_bases > G.max_paired_bases) return LZGPU_NH_PAIRED_LIMIT;
+            }
         }
         if (cut) for (size_t e = 0; e < entries.size(); e++)    // for the scan of the next window
             if (!entries[e].speculated && entries[e].near_slot < slot_align.size()) near_align[entries[e].anchor_ix] = slot_align[entries[e].near_slot];

@@ -46,6 +46,7 @@ struct LzGappedParams {
     const u32* sep2 = nullptr; u32 n_sep2 = 0;
     bool strands_differ = false, inhibit_trivial = false;
     bool all_bounds = false;               // low-scoring alignments bound later extensions too (:1411-1429)
+    u64 max_paired_bases = 0;              // :1441-1459 (0: no limit); exceeded -> LZGPU_NH_PAIRED_LIMIT
 };
 
 struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };

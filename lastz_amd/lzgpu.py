@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("LZGPU_LIB") or os.path.join(_HERE, "liblzgpu.so")   #
 MAX_PARTS, MAX_PROBES = 16, 128
 
 NH_REASONS = {1: "SEED", 2: "SCORE_CLASSES", 3: "HITS_OVERFLOW", 4: "HSP_OVERFLOW", 5: "SIZE",
-              6: "IDENTICAL", 7: "UNSUPPORTED"}
+              6: "IDENTICAL", 7: "UNSUPPORTED", 8: "PAIRED_LIMIT"}
 
 
 class SeedDesc(C.Structure):
@@ -42,7 +42,7 @@ class GappedArgs(C.Structure):
                 ("sep1", C.c_void_p), ("n_sep1", C.c_uint32), ("sep2", C.c_void_p), ("n_sep2", C.c_uint32),
                 ("strands_differ", C.c_int32), ("inhibit_trivial", C.c_int32),
                 ("t_off", C.c_uint32), ("t_len", C.c_uint32), ("q_off", C.c_uint32), ("q_len", C.c_uint32),
-                ("all_bounds", C.c_int32), ("no_trim", C.c_int32)]
+                ("all_bounds", C.c_int32), ("no_trim", C.c_int32), ("max_paired_bases", C.c_uint64)]
 
 
 class WindowSearchArgs(C.Structure):
@@ -250,10 +250,10 @@ class Lib:
     # ---- B3
     def _gapped_args(self, keep, sub, anchors, q=None, slot=-1, gap_open=400, gap_extend=30, ydrop=9400, score_thresh=3000,
                      traceback_bytes=0, reduce=True, sep1=None, sep2=None, strands_differ=False, inhibit_trivial=False,
-                     t_off=0, t_len=0, q_off=0, q_len=0, all_bounds=False, no_trim=False):
+                     t_off=0, t_len=0, q_off=0, q_len=0, all_bounds=False, no_trim=False, max_paired_bases=0):
         a = GappedArgs()
         a.strands_differ, a.inhibit_trivial = int(strands_differ), int(inhibit_trivial)
-        a.all_bounds, a.no_trim = int(all_bounds), int(no_trim)
+        a.all_bounds, a.no_trim, a.max_paired_bases = int(all_bounds), int(no_trim), int(max_paired_bases)
         a.t_off, a.t_len, a.q_off, a.q_len = t_off, t_len, q_off, q_len
         if sep1 is not None:
             sep1 = np.ascontiguousarray(sep1, dtype=np.uint32); a.sep1, a.n_sep1 = sep1.ctypes.data, len(sep1)

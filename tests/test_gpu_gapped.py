@@ -224,3 +224,17 @@ def test_untrimmed_ends_and_all_bounds(gpu, opt):
     for name, (t, q) in T._option_pairs().items():
         mine, _ = _gpu_blocks(gpu, t, [q], **kw)
         assert mine == H.lav_blocks(os.path.join(H.GOLDEN, f"options_{opt}_{name}.lav")), (opt, name)
+
+
+def test_paired_bases_limit(gpu):
+    """maxPairedBases (--querydepth, src/gapped_extend.c:1441-1459): below the limit the stage is the stage without a
+    limit; the moment the alignments pair more bases than allowed the call declines (LZGPU_NH_PAIRED_LIMIT = 8) so that
+    the reference's own routine warns and keeps / discards"""
+    t, q = H.load_case("synth200k")
+    gold = H.lav_blocks(os.path.join(H.GOLDEN, "synth200k.lav"))
+    paired = sum(x[2] - x[0] + 1 for st in gold for b in st[2] for x in b["l"])          # bases of all gap-free pieces, both strands
+    mine, _ = _gpu_blocks(gpu, t, [q], max_paired_bases=paired)
+    assert mine == gold
+    with pytest.raises(lzgpu.NotHandled) as e:
+        _gpu_blocks(gpu, t, [q], max_paired_bases=1000)
+    assert e.value.rc == 8

@@ -189,3 +189,26 @@ def test_bench_pair_lav_fingerprint(tmp_path):
     assert err.count("[lzgpu] gapped: done on the GPU") == 2 and err.count("[lzgpu] search: done on the GPU") == 2
     assert out.count("\na {") == gold["lav_blocks"]
     assert bench.lav_fingerprint(out) == gold["lav_sha"]
+
+
+@needs_bins
+@pytest.mark.parametrize("flags,notes", [(["--noytrim"], {"done on the GPU": 2}),
+                                         (["--allgappedbounds", "--gappedthresh=9000"], {"done on the GPU": 2}),
+                                         (["--querydepth=keep,nowarn:1.5"], {"done on the GPU": 2}),
+                                         (["--querydepth=keep,nowarn:0.02"], {"declined, reference path": 1})],
+                         ids=["noytrim", "allgappedbounds", "querydepth-not-reached", "querydepth-reached"])
+def test_gapped_options_that_used_to_be_declined(sandbox, flags, notes):
+    """round 3: untrimmed ends, all alignments as bounds and a limit on the paired bases run on the device (the limit,
+    once exceeded, hands the stage back to the reference's routine, which warns and truncates as --querydepth asks);
+    byte-identical to the pristine binary"""
+    t, q = seqio.synth_pair(300_000, 250_000, seed=43, block_min=400, block_max=6000)
+    seqio.write_fasta(sandbox / "to.fa", [("target", t)]); seqio.write_fasta(sandbox / "qo.fa", [("query", q)])
+    args = ["to.fa", "qo.fa", "--ydrop=9430", "--format=maf"] + flags
+    out, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+    ref, _ = run(REF_BIN, args, sandbox)
+    drop = lambda s: "".join(l for l in s.splitlines(True) if not l.startswith("#"))
+    assert drop(out) == drop(ref) and out.count("\na score=") > 3
+    for how, n in notes.items():
+        assert err.count("[lzgpu] gapped: " + how) >= n, err[-1500:]
+    if "declined, reference path" not in notes:
+        assert "[lzgpu] gapped: declined" not in err and "[lzgpu] gapped: reference path" not in err
