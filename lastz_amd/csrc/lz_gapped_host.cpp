@@ -409,9 +409,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // lasts as long as its longest DP, so the long ones should be among the first resident.
     std::vector<u32> ext_l, ext_r;
     std::unordered_map<u32, u32> ext_of;                       // anchor index -> slot
+    std::vector<std::pair<s64, s64>> slot_anchor;              // LZGPU_HOSTPROF: (diagonal, pos1) of a slot's selected anchor
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
-        jobs.clear(); entries.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear();
+        jobs.clear(); entries.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear(); slot_anchor.clear();
         for (u32 t : touched) chosen_grid[t].clear();
         touched.clear();
         u32 insured = 0;
@@ -454,6 +455,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             ext_of[j] = (u32)ext_l.size();
             { const size_t gi = (size_t)(cell - cell_lo); if (chosen_grid[gi].empty()) touched.push_back((u32)gi); chosen_grid[gi].push_back({ dg, (s64)a1, (u32)ext_l.size() }); }
             ext_l.push_back(0); ext_r.push_back(0);
+            if (prof) slot_anchor.push_back({ dg, (s64)a1 });
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
@@ -514,7 +516,18 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (prof) t_c_lr += now() - tq0;
             if (ok < 0) return LZGPU_ERR_STATE;
             if (ok == 0) { cache.erase(aix); continue; }       // lies on an alignment committed meanwhile
-            if (!entries[e].speculated) { next = aix; cut = true; break; }    // needs a DP: head of the next window
+            if (!entries[e].speculated) {                       // needs a DP: head of the next window
+                // (On the bench pair every strand has one or two of these: an anchor a few diagonals beside the long
+                // alignment of the selected anchor it was found near, 8 kbp along it.  Its DP is bounded by that very
+                // alignment, so it cannot be launched before the alignment exists: the second round is inherent.  A rule
+                // that also speculated the first anchor beyond every 1.5 kbp gap in the run of deferred anchors found
+                // nothing to add here and cost 5 ms of sorting -- not kept.)
+                if (prof && entries[e].near_slot < slot_anchor.size())
+                    fprintf(stderr, "[lzgpu hostprof] window cut at anchor %u (score %d): deferred near a selected anchor %lld diagonals and %lld bases away, not on its alignment\n",
+                            aix, anchors[aix].s, (long long)((s64)anchors[aix].pos1 - (s64)anchors[aix].pos2 - slot_anchor[entries[e].near_slot].first),
+                            (long long)((s64)anchors[aix].pos1 - slot_anchor[entries[e].near_slot].second));
+                next = aix; cut = true; break;
+            }
             auto it = cache.find(aix);
             const Cached& sp = it->second;
             const LzDpResult& rl = sp.rl; const LzDpResult& rr = sp.rr;
