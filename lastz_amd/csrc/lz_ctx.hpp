@@ -93,7 +93,7 @@ struct LzCtx {
     std::vector<u64> last_order;      // two sort words per HSP of the last search
     int min_scan_mode = 0;            // lzgpu_set_scan_mode
     int last_scan_mode = -1;          // phase-A scan mode of the last search (0/1: look-up tables without/with special masks, 2: byte codes)
-    u64 hit_capacity = (1ull << 30);    // hits per chunk (LZGPU_HIT_CAPACITY): 2^28 -> 2^30 took 10 ms off the 50 Mbp step (fewer launches, fewer passes over the sorted words); 21 GiB of chunk buffers
+    u64 hit_capacity = (1ull << 31);    // hits per chunk (LZGPU_HIT_CAPACITY): 2^28 -> 2^30 took 10 ms off the 50 Mbp step (fewer launches, fewer passes over the sorted words), 2^30 -> 2^31 another 5.5 (a 50 Mbp strand is one chunk); the buffers follow the largest chunk: 21 bytes per hit, 42 GiB at most
     u64 hsp_capacity = (1ull << 24);
 
     lz_counters counters = {};
