@@ -17,3 +17,5 @@ python tools/pmc_fetch_write.py "$O/pmc_f/**/*counter_collection.csv" "$O/pmc_w/
 head -12 $O/pmc_fetch_write.csv; head -12 $O/kernel_stats.csv
 rm -rf $O/stats $O/pmc_f $O/pmc_w
 LZGPU_OVERLAP=1 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cli --no-gapped > $O/bench_overlap.json 2> $O/bench_overlap.err
+# the N > 1 code path of bench.py with two ranks on this one GPU (gloo stands in for RCCL, which refuses two ranks on one device): a smoke run, not a measurement
+LZ_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --tlen-multi 5000000 --q-units 3 --q-unit-len 2000000 > $O/bench_two_ranks_gloo_smoke.json 2> $O/bench_two_ranks.err; tail -c 700 $O/bench_two_ranks_gloo_smoke.json
