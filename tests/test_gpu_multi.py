@@ -103,8 +103,9 @@ def test_a_rank_parses_only_what_it_owns_at_size(tmp_path):
         assert "copied to the host for a reference routine" not in errs[r]
         assert errs[r].count("contains an empty sequence") == 1
     print("single process %.1f s; ranks %s s for %s owned bases" % (single_s, ["%.1f" % x for x in info["rank_seconds"]], info["owned_bases"]))
-    # (two ranks share ONE GPU here, so their GPU stages take turns: the wall clocks only show that nothing is worse)
-    assert max(info["rank_seconds"]) < 1.2 * single_s
+    # (two ranks share ONE GPU here and the table travels through a file instead of xGMI, so the wall clocks say
+    # nothing about scaling: a loose bound against pathologies only)
+    assert max(info["rank_seconds"]) < 3.0 * single_s
 
 
 @needs_bins
