@@ -39,6 +39,7 @@ struct SeqSlot {                    // a sequence resident in HBM
     DevBuf nib;                     // 4-bit class codes, two bases per byte (byte-code scans; built when all classes are < 8)
     bool   have_nib = false;
     DevBuf two, spc;                // 2-bit codes and the 1-bit "not A,C,G,T" mask (lz_lut.hpp), rebuilt with the codes
+    DevBuf two_x, spc_x;            // the same bytes in half-overlapping 64-byte blocks (k_overlap32; read by k_scan_hits for the target)
     DevBuf occ_dev;                 // [256] u32: which byte values occur
     u8     occ[256] = { 0 };        // ... on the host
     bool   has_special = false;     // some byte of the sequence is outside the 2-bit alphabet
@@ -121,6 +122,7 @@ struct LzLutParams; struct LzLutEntry;
 #define LZ_PP_TILE_HOST 16384       // hits per tile of k_hist / k_partition (sizes the partition histogram); 8192 with 512 lanes: 24.5 ms per step, 16384 with 1024: 21.7
 #endif
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256);
+int lzk_overlap32(LzCtx& c, const u8* src, u8* dst, size_t nblocks);
 int lzk_hist(LzCtx& c, const u8* bins, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);
 int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,

@@ -50,6 +50,8 @@ struct alignas(8) LzLutEntry { u32 ab; u32 sc; };          // ab = A (u16) | B' 
 struct LzLutParams {
     const u8* t2; const u8* q2;                   // Gray 2-bit codes: base i at bits 2*((i+PAD2)&3) of byte (i+PAD2)>>2
     const u8* tsp; const u8* qsp;                 // special masks: base i at bit (i+PAD2)&7 of byte (i+PAD2)>>3
+    const u8* t2x; const u8* tspx;                // the target's two arrays once more, in 64-byte blocks that overlap by half
+                                                  // (block k = bytes [32k, 32k+64) of the plain array; seed_kernels.hip::lz_scan_fetch)
     s32 xdrop;
 };
 

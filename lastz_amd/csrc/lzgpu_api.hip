@@ -200,6 +200,7 @@ extern "C" void lzgpu_shutdown(void)
     for (int k = 0; k < LZ_SETS; k++) { DevBuf* sb[] = { &c.bins[k], &c.keys[k], &c.recs[k], &c.bin_base[k], &c.hist[k], &c.hist_part[k], &c.summ[k], &c.scan_tasks[k], &c.scan_ntasks[k] }; for (DevBuf* b : sb) b->release(); }
     for (auto& kv : c.queries) { kv.second.raw.release(); kv.second.code.release(); kv.second.dp.release(); kv.second.nib.release(); kv.second.two.release(); kv.second.spc.release(); kv.second.occ_dev.release(); }
     c.target.dp.release(); c.target.nib.release(); c.target.two.release(); c.target.spc.release(); c.target.occ_dev.release();
+    c.target.two_x.release(); c.target.spc_x.release();
     lz_release_statics();
     c.queries.clear();
     (void)hipStreamDestroy(c.stream);
@@ -265,12 +266,19 @@ static int slot_encode(LzCtx& c, SeqSlot& s, const u8 cls[256], DevBuf& cls_dev)
     }
     // 2-bit codes, special mask and the set of byte values that occur (phase A on look-up tables, lz_lut.hpp)
     const u32 nmask = (u32)(((size_t)s.len + 2 * LZ_PAD2 + 7) / 8 + 16);
-    if ((rc = s.two.ensure((size_t)nmask * 2 + 32))) return rc;
-    if ((rc = s.spc.ensure((size_t)nmask + 32))) return rc;
+    if ((rc = s.two.ensure((size_t)nmask * 2 + 96))) return rc;       // (+ what k_overlap32's last block reads past the end)
+    if ((rc = s.spc.ensure((size_t)nmask + 96))) return rc;
     if ((rc = s.occ_dev.ensure(256 * 4))) return rc;
-    LZ_HIP(hipMemsetAsync(s.two.p, 0, (size_t)nmask * 2 + 32, c.stream));
-    LZ_HIP(hipMemsetAsync(s.spc.p, 0xFF, (size_t)nmask + 32, c.stream));
+    LZ_HIP(hipMemsetAsync(s.two.p, 0, (size_t)nmask * 2 + 96, c.stream));
+    LZ_HIP(hipMemsetAsync(s.spc.p, 0xFF, (size_t)nmask + 96, c.stream));
     if ((rc = lzk_pack2(c, s.code_base(), s.raw_base(), s.len, s.two.as<u8>(), s.spc.as<u8>(), nmask, s.occ_dev.as<u32>()))) return rc;
+    if (&s == &c.target) {                                     // (the target only: k_scan_hits reads these instead of the plain arrays)
+        const size_t nb2 = ((size_t)nmask * 2 + 31) / 32, nb1 = ((size_t)nmask + 31) / 32;
+        if ((rc = s.two_x.ensure(nb2 * 64 + 64))) return rc;
+        if ((rc = s.spc_x.ensure(nb1 * 64 + 64))) return rc;
+        if ((rc = lzk_overlap32(c, s.two.as<u8>(), s.two_x.as<u8>(), nb2))) return rc;
+        if ((rc = lzk_overlap32(c, s.spc.as<u8>(), s.spc_x.as<u8>(), nb1))) return rc;
+    }
     u32 flags[256];
     LZ_HIP(hipMemcpyAsync(flags, s.occ_dev.p, sizeof(flags), hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
@@ -589,6 +597,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     // (mode 0 / 1 = without / with special-byte masks), else the byte-code scans (mode 2)
     LzLutParams Q;
     Q.t2 = c.target.two.as<u8>(); Q.q2 = qs->two.as<u8>(); Q.tsp = c.target.spc.as<u8>(); Q.qsp = qs->spc.as<u8>(); Q.xdrop = a->xdrop;
+    Q.t2x = c.target.two_x.as<u8>(); Q.tspx = c.target.spc_x.as<u8>();
     int mode = 2;
     if (a->extend) {
         s32 M4[16];

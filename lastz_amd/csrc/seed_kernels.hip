@@ -459,6 +459,25 @@ k_byte_presence(const u8* __restrict__ raw, u32 len, u32* __restrict__ flags)
     __syncthreads();
     if (f[threadIdx.x]) flags[threadIdx.x] = 1;
 }
+// Block k of dst = bytes [32k, 32k + 64) of src: every run of up to 32 bytes of src lies inside ONE 64-byte line of
+// dst (the block its first byte's 32-byte half starts).  Phase A reads 31-32 consecutive bytes of the target's 2-bit
+// array around every hit, at a random place: from the plain array that is 1.5 cache lines per hit on average, and the
+// scan kernel runs exactly as fast as its CU's L1 can have lines in flight (64 x 64 B per ~460 cycles).
+__global__ void __launch_bounds__(LZ_TPB)
+k_overlap32(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t nchunks)
+{
+    const size_t v = (size_t)blockIdx.x * LZ_TPB + threadIdx.x;           // 16-byte chunk of dst: block v / 4, quarter v % 4
+    if (v < nchunks) dst[v] = src[2 * (v >> 2) + (v & 3u)];
+}
+int lzk_overlap32(LzCtx& c, const u8* src, u8* dst, size_t nblocks)
+{
+    const size_t nchunks = nblocks * 4;
+    hipLaunchKernelGGL(k_overlap32, dim3((unsigned)((nchunks + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, c.stream,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), nchunks);
+    LZ_HIP(hipGetLastError());
+    return 0;
+}
+
 int lzk_pack2(LzCtx& c, const u8* code_base, const u8* raw_base, u32 len, u8* two, u8* spc, u32 nmask, u32* flags256)
 {
     LZ_HIP(hipMemsetAsync(flags256, 0, 256 * 4, c.stream));
@@ -653,7 +672,26 @@ __device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzL
 {
     const u32 pos2 = (u32)key, pos1 = pos2 + (u32)(key >> 32);
     const s32 diag = (s32)(u32)(key >> 32);
+#if defined(LZ_SCAN_PLAIN_TARGET)        // A/B aid: the target windows from the plain arrays (1.5 lines per hit)
     lz_lut_fetch<false, SP>(Q, pos1, diag, rawl); lz_lut_fetch<true, SP>(Q, pos1, diag, rawr);
+#else
+    {
+        // lz_lut_fetch's loads, the target's from the half-overlapping blocks: the left window starts at byte bl, the right
+        // one at br = bl + 15 or 16, together at most 32 bytes: one line of t2x (block bl / 32, offset bl % 32)
+        const u32 stl = pos1 - 1u + (u32)LZ_PAD2, str = pos1 + (u32)LZ_PAD2;
+        const u32 bl = (stl >> 2) - 15u, br = str >> 2;
+        const u32 ol = bl + (bl & ~31u);
+        rawl.tv = lz_load16(Q.t2x + ol); rawr.tv = lz_load16(Q.t2x + (ol + (br - bl)));
+        const u32 sql = stl - (u32)diag, sqr = str - (u32)diag;
+        rawl.qv = lz_load16(Q.q2 + ((sql >> 2) - 15u)); rawr.qv = lz_load16(Q.q2 + (sqr >> 2));
+        if constexpr (SP) {
+            const u32 ml = (stl >> 3) - 14u, mr = str >> 3;           // (mr - ml is 14 or 15: at most 31 bytes)
+            const u32 oml = ml + (ml & ~31u);
+            rawl.tm = lz_load16(Q.tspx + oml); rawr.tm = lz_load16(Q.tspx + (oml + (mr - ml)));
+            rawl.qm = lz_load16(Q.qsp + ((sql >> 3) - 14u)); rawr.qm = lz_load16(Q.qsp + (sqr >> 3));
+        }
+    }
+#endif
 #if defined(LZ_EXP_NO_LEFT_TARGET)      // timing experiments only (results are wrong): what the random target fetches cost
     rawl.tv = rawr.tv;
 #elif defined(LZ_EXP_NO_TARGET)
