@@ -1071,9 +1071,9 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 #endif
 #define LZ_S2_SORTW   (LZ_S2_TPB / 64 - LZ_S2_WALKW)     // 12 sorting waves
 #ifndef LZ_S2_ROUNDS
-#define LZ_S2_ROUNDS  6                                  // records per sorter lane and tile (3: 26.7, 4: 24.6, 6: 22.8 ms per step)
+#define LZ_S2_ROUNDS  7                                  // records per sorter lane and tile (3: 26.7, 4: 24.6, 6: 22.8 ms per step; 6 -> 7 with one chunk per strand: 20.8 -> 20.1; 8 does not fit the LDS)
 #endif
-#define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 4608
+#define LZ_S2_TILE    (LZ_S2_SORTW * 64 * LZ_S2_ROUNDS)  // 5376
 struct LzSettle2Shared {
     s32 tab[LZ_NCLASS * LZ_NCLASS];
     u64 rec[2][LZ_S2_TILE + LZ_ST_BATCH];                // the placed tiles (bucket-major), two take turns
