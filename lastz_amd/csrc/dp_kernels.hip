@@ -125,7 +125,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 #ifndef LZ_DP_WPE
 #define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow: six DPs of four waves per CU
 #endif
-template <bool NOTRIM>
+template <bool NOTRIM, bool BOUNDS>
 __global__ void __launch_bounds__(LZ_DP_LANES, LZ_DP_WPE)
 k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
         const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
@@ -143,11 +143,11 @@ k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* _
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
     const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its snapshot, its query)
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
-template <bool NOTRIM>
+template <bool NOTRIM, bool BOUNDS>
 __global__ void __launch_bounds__(LZ_DP_LANES)
 k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
              const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u8* __restrict__ rings)
@@ -163,7 +163,7 @@ k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJ
     const LzDpJob J = jobs[j];
     const LzDpProblem pb = problems[J.problem];
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -206,6 +206,7 @@ struct HipDpExec : LzDpExecutor {
     u64 wide_runs = 0;
     u32 tab_rows = LZ_NCLASS;                                  // row classes of the score matrix in use (k_ydrop's dynamic LDS)
     const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
+    bool bounds = true;                                         // some problem of the launch has earlier alignments (else: k_ydrop<.., false>)
     // Traceback slots.  A retry gives every DP the same (larger) slot; the first try sizes each DP's slot from the
     // host's guess of the rows it will sweep (est_rows, lz_gapped_host.cpp: the deferred anchors around the DP's
     // anchor): on the bench pair rows = 1.2 x est_rows (median; 2.2 x at the 90th percentile) and a row has ~430
@@ -251,11 +252,13 @@ struct HipDpExec : LzDpExecutor {
             if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
             wide_runs += n;
             c.timer.begin("k_ydrop_wide", c.stream);
-            hipLaunchKernelGGL(P.no_trim ? k_ydrop_wide<true> : k_ydrop_wide<false>, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+            hipLaunchKernelGGL(P.no_trim ? (bounds ? k_ydrop_wide<true, true> : k_ydrop_wide<true, false>) : (bounds ? k_ydrop_wide<false, true> : k_ydrop_wide<false, false>),
+                               dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.timer.begin("k_ydrop", c.stream);
-            hipLaunchKernelGGL(P.no_trim ? k_ydrop<true> : k_ydrop<false>, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
+            hipLaunchKernelGGL(P.no_trim ? (bounds ? k_ydrop<true, true> : k_ydrop<true, false>) : (bounds ? k_ydrop<false, true> : k_ydrop<false, false>),
+                               dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
         c.timer.end(c.stream);
@@ -366,6 +369,7 @@ struct HipDpExec : LzDpExecutor {
             oa += a; os += g;
             for (LzDpJob J : *items[p].jobs) { J.problem = (u32)p; jobs.push_back(J); }
         }
+        bounds = na != 0;
         LZ_HIP(hipMemcpyAsync(g_dp.problems.p, pb.data(), pb.size() * sizeof(LzDpProblem), hipMemcpyHostToDevice, c.stream));
         problems_dev = g_dp.problems.as<LzDpProblem>();
         std::vector<LzDpResult> res(jobs.size());
