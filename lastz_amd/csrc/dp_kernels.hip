@@ -63,6 +63,8 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         if ((__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave) f();     // a scalar branch: one wave, all its lanes
         __syncthreads();
     }
+    template <class F> __device__ __forceinline__ void every_wave(F&& f) { f(); }           // the serial piece on every wave's own copy of the state: no barrier
+    __device__ __forceinline__ bool lead_here() const { return (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave; }
     __device__ __forceinline__ s32 uni(s32 v) { return __builtin_amdgcn_readfirstlane(v); }
     __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((s32)v); }
 

@@ -393,9 +393,15 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
 
     const u64 t0 = LZ_CLOCK();
     const u64 rt0 = LZ_REALTIME();
-    LzDpCtl ct;                                                 // lane 0's
+    // REPL: every wave keeps its own copy of the sweep state and runs the serial piece itself, on identical inputs.  One
+    // wave doing it for all costs a barrier, sixteen words written to LDS and read back by the others, per row; the
+    // copies cost nothing (the other three waves were waiting).  What the piece writes to LDS is the same from every
+    // wave and each wave reads its own writes; only the list of active segments is updated in place, so this is for
+    // problems without bounds.  Global stores stay with one wave.
+    constexpr bool REPL = !BOUNDS;
+    LzDpCtl ct;                                                 // lane 0's (REPL: every wave's)
     // ---- set-up + row 0 (:3500-3605)
-    x.leader([&]() {
+    auto setup = [&]() {
         s32 L = 0, R = (s32)N + 1;
         if (J.left_seg >= 0)  { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.left_seg]);  L = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) L -= LZ_SDIFF(g.b1, J.anchor1); }
         if (J.right_seg >= 0) { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.right_seg]); R = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) R -= LZ_SDIFF(g.b1, J.anchor1); }
@@ -419,12 +425,13 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         if (n0 + LZ_DP_LANES + 72 > SH::RING) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; }
         if (n0 > J.tb_cap || J.row_cap < 2) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; }
         ct.LY = 0; ct.RY = n0; ct.tb_used = n0; ct.cells = n0;
-        if (!ct.done) trow[0] = 0;
+        if (!ct.done && (!REPL || x.lead_here())) trow[0] = 0;
         ct.b_hi = 1; sh.trow_cur = 0;
         while (ct.RY + 2 > ct.b_hi) ct.b_hi += LZ_DP_LANES;     // columns [1, b_hi) are staged by the next phase
         ct.max_col = n0 ? n0 - 1 : 0;
         sh.done = ct.done; sh.b_hi = ct.b_hi; sh.ry_iter = n0; sh.row = 0; sh.LY = 0; sh.best = 0; sh.n_act = 0; sh.extra = 0;
-    });
+    };
+    if (REPL) x.every_wave(setup); else x.leader(setup);
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
             // the mask stamps are row numbers: a previous job's stamps must not survive in the LDS block
@@ -448,13 +455,13 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     bool swept = false;
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
     u64 tl[5] = { 0, 0, 0, 0, 0 };
-    while (!sh.done) {
+    while (!(REPL ? x.uni(ct.done) : sh.done)) {
         const u64 ts = LZ_PHASE_CLOCK();
-        x.leader([&]() {
+        // (published at the end, in one block -- or, REPL, simply kept)
+        u32 p_fill_n = 0, p_fill_base = 0, p_fill_trow = 0, p_stage_lo = ct.b_hi, p_stage_a = 0, p_trow_cur = 0, p_ry_iter = 0, p_cpl = 0, p_extra = 0;
+        s32 p_fill_i = 0;
+        auto control = [&]() {
             u64 q0 = LZ_PHASE_CLOCK(), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
-            // (published at the end, in one block)
-            u32 p_fill_n = 0, p_fill_base = 0, p_fill_trow = 0, p_stage_lo = ct.b_hi, p_stage_a = 0, p_trow_cur = 0, p_ry_iter = 0, p_cpl = 0, p_extra = 0;
-            s32 p_fill_i = 0;
             [&]() {
             u32 extra = 0;
             if (swept) {
@@ -485,7 +492,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                     for (u32 k = 0; k < np; k++) {
                         const s32 iv = i_last - (s32)k * gapE;
                         sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
-                        tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
+                        if (!REPL || x.lead_here()) tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
                     }
                 } else { p_fill_n = np; p_fill_base = RY - np; p_fill_i = i_last; p_fill_trow = trow_cur; extra = 1; }
                 tb_used += np;
@@ -520,34 +527,45 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             if ((u64)ct.tb_used + (u64)tb_needed > (u64)J.tb_cap) { ct.status = LZ_DP_TB_SLOT; ct.done = 1; return; }
             if (width + (u32)P.ydrop_tail + LZ_DP_LANES + 72 > SH::RING) { ct.status = LZ_DP_TOO_WIDE; ct.done = 1; return; }
             if (ct.row + 1 >= J.row_cap) { ct.status = LZ_DP_ROW_SLOT; ct.done = 1; return; }
-            trow[ct.row] = p_trow_cur = ct.tb_used - ct.LY;     // tbRow[row], :3662 (u32 wrap intended)
+            p_trow_cur = ct.tb_used - ct.LY;                    // tbRow[row], :3662 (u32 wrap intended)
+            if (!REPL || x.lead_here()) trow[ct.row] = p_trow_cur;
             p_ry_iter = ct.RY;
             p_cpl = (width + LZ_DP_LANES - 1) / LZ_DP_LANES;
             }();
-            sh.row = ct.row; sh.LY = ct.LY; sh.ry_iter = p_ry_iter; sh.cpl = p_cpl;
-            sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.n_act = ct.n_act; sh.done = ct.done;
-            sh.extra = p_extra; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
-            sh.stage_lo = p_stage_lo; sh.stage_a = p_stage_a; sh.fill_i = p_fill_i; sh.b_hi = ct.b_hi;
+            if (!REPL) {
+                sh.row = ct.row; sh.LY = ct.LY; sh.ry_iter = p_ry_iter; sh.cpl = p_cpl;
+                sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.n_act = ct.n_act; sh.done = ct.done;
+                sh.extra = p_extra; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
+                sh.stage_lo = p_stage_lo; sh.stage_a = p_stage_a; sh.fill_i = p_fill_i; sh.b_hi = ct.b_hi;
+            }
             const u64 q5 = LZ_PHASE_CLOCK();
             if (q1 < q0) q1 = q0; if (q2 < q1) q2 = q1; if (q3 < q2) q3 = q2; if (q4 < q3) q4 = q3;
             tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += q5 - q4;
-        });
-        if (sh.done) break;
-        if (sh.extra) x.phase([&](int lane, LzDpLane&) {
-            const u32 np = sh.fill_n, base = sh.fill_base;
-            for (u32 k = (u32)lane; k < np; k += LZ_DP_LANES) {
-                const s32 iv = sh.fill_i - (s32)k * gapE;
-                sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
-                tb[(u32)(sh.fill_trow + base + k)] = LZ_C_FROM_I;
-            }
-            for (u32 col = sh.stage_lo + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES)
-                sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
-            if (sh.stage_a) {
-                const u32 r2 = sh.stage_a + (u32)lane;
-                sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
-            }
-        });
-        row = x.uni(sh.row); LY0 = x.uni(sh.LY); RYi = x.uni(sh.ry_iter); cpl = x.uni(sh.cpl); best0 = x.uni(sh.best); trow_cur = x.uni(sh.trow_cur);
+        };
+        if (REPL) x.every_wave(control); else x.leader(control);
+        if (REPL ? x.uni(ct.done) != 0u : sh.done != 0u) break;
+        // the rare parallel pieces of the row set-up: a long run of overhang cells, the next columns' / rows' classes
+        const u32 e_on = REPL ? p_extra : sh.extra;
+        if (e_on) {
+            const u32 e_fill_n = REPL ? p_fill_n : sh.fill_n, e_fill_base = REPL ? p_fill_base : sh.fill_base, e_fill_trow = REPL ? p_fill_trow : sh.fill_trow;
+            const s32 e_fill_i = REPL ? p_fill_i : sh.fill_i;
+            const u32 e_stage_lo = REPL ? p_stage_lo : sh.stage_lo, e_b_hi = REPL ? ct.b_hi : sh.b_hi, e_stage_a = REPL ? p_stage_a : sh.stage_a;
+            x.phase([&](int lane, LzDpLane&) {
+                for (u32 k = (u32)lane; k < e_fill_n; k += LZ_DP_LANES) {
+                    const s32 iv = e_fill_i - (s32)k * gapE;
+                    sh.cc[LZ_RING(e_fill_base + k)] = iv; sh.dd[LZ_RING(e_fill_base + k)] = iv - gapOE;
+                    tb[(u32)(e_fill_trow + e_fill_base + k)] = LZ_C_FROM_I;
+                }
+                for (u32 col = e_stage_lo + (u32)lane; col < e_b_hi; col += LZ_DP_LANES)
+                    sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
+                if (e_stage_a) {
+                    const u32 r2 = e_stage_a + (u32)lane;
+                    sh.aa[lane] = (r2 <= M) ? (u8)(lz_dp_a(P, J, r2) & 31u) : 0;
+                }
+            });
+        }
+        if (REPL) { row = x.uni(ct.row); LY0 = x.uni(ct.LY); RYi = x.uni(p_ry_iter); cpl = x.uni(p_cpl); best0 = x.uni(ct.best); trow_cur = x.uni(p_trow_cur); }
+        else { row = x.uni(sh.row); LY0 = x.uni(sh.LY); RYi = x.uni(sh.ry_iter); cpl = x.uni(sh.cpl); best0 = x.uni(sh.best); trow_cur = x.uni(sh.trow_cur); }
         swept = true;
         const bool any_active = BOUNDS && sh.n_act != 0;
         const u32 row_stamp = SH::stamp(row);

@@ -14,6 +14,8 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
     template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
     template <class F> void step(F&& f)  { for (int l = LZ_DP_LANES - 1; l >= 0; l--) f(l, lanes[l]); }   // no barrier on the GPU: any lane order must do
     template <class F> void leader(F&& f) { f(); }
+    template <class F> void every_wave(F&& f) { f(); }          // (one copy of the control state here)
+    bool lead_here() const { return true; }
     int lead_lane() const { return 0; }
     s32 uni(s32 v) { return v; }
     u32 uni(u32 v) { return v; }
