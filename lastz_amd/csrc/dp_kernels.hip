@@ -4,6 +4,7 @@
 // CPU phase emulator used by the no-GPU tests); the anchor ordering / commit logic is in
 // lz_gapped_host.cpp.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -127,15 +128,18 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 #ifndef LZ_DP_WPE
 #define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow: six DPs of four waves per CU
 #endif
+#ifndef LZ_DP_WPE_FREE
+#define LZ_DP_WPE_FREE 7               // ... and seven of the problems without earlier alignments (no mask stamps: 22 KiB per DP)
+#endif
 template <bool NOTRIM, bool BOUNDS>
-__global__ void __launch_bounds__(LZ_DP_LANES, LZ_DP_WPE)
+__global__ void __launch_bounds__(LZ_DP_LANES, BOUNDS ? LZ_DP_WPE : LZ_DP_WPE_FREE)
 k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
         const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
 {
     // LDS per DP decides how many DPs share a CU (160 KiB): 25.5 KiB of sweep row and state + the rows of the class
     // table the matrix really has (dynamic: 1 KiB for HOXD70's 8 row classes) = six DPs per CU (round 2: 34 KiB with
     // a full 32 x 32 table and 32-bit mask stamps, four per CU)
-    __shared__ LzDpShared sh;
+    __shared__ typename std::conditional<BOUNDS, LzDpShared, LzDpSharedNoMask>::type sh;
     extern __shared__ __align__(16) s32 tab[];
     for (u32 k = threadIdx.x; k < tab_rows * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
     __syncthreads();

@@ -126,6 +126,18 @@ template <u32 W> struct LzDpRingLds {
     u8  lk[W];                            // traceback link of the current row
     u8  bb[W];                            // B (query) score classes of the band's columns
 };
+// the ring of a problem without earlier alignments (lz_dp_run<.., BOUNDS = false>): nothing is ever masked, no stamps --
+// 4 KiB less per DP, seven DPs per CU instead of six
+template <u32 W> struct LzDpRingLdsNoMask {
+    static constexpr u32 RING = W;
+    static constexpr bool STAMP_WRAPS = false;
+    typedef unsigned short stamp_t;
+    static LZ_HD u32 stamp(u32 row) { return row; }
+    s32 cc[W], dd[W];
+    stamp_t mk[1];                        // (never touched)
+    u8  lk[W];
+    u8  bb[W];
+};
 struct LzDpRingHbm {
     static constexpr u32 RING = LZ_DP_WIDEW;
     static constexpr bool STAMP_WRAPS = false;
@@ -154,6 +166,7 @@ struct LzDpSharedBase {
 };
 template <class Ring> struct LzDpSharedT : LzDpSharedBase, Ring {};
 typedef LzDpSharedT<LzDpRingLds<LZ_DP_MAXW>> LzDpShared;
+typedef LzDpSharedT<LzDpRingLdsNoMask<LZ_DP_MAXW>> LzDpSharedNoMask;
 typedef LzDpSharedT<LzDpRingHbm> LzDpSharedWide;
 
 // Sweep state of one DP.  Only lane 0 reads and writes it, so it lives in that lane's registers:
@@ -435,7 +448,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     if (!sh.done) {
         x.phase([&](int lane, LzDpLane&) {
             // the mask stamps are row numbers: a previous job's stamps must not survive in the LDS block
-            for (u32 k = (u32)lane; k < SH::RING; k += LZ_DP_LANES) sh.mk[k] = 0;
+            if (BOUNDS) for (u32 k = (u32)lane; k < SH::RING; k += LZ_DP_LANES) sh.mk[k] = 0;
             for (u32 col = 1 + (u32)lane; col < sh.b_hi; col += LZ_DP_LANES) sh.bb[LZ_RING(col)] = (col <= N) ? (u8)(lz_dp_b(P, J, col) & 31u) : 0;
             sh.aa[lane] = (1 + (u32)lane <= M) ? (u8)(lz_dp_a(P, J, 1 + (u32)lane) & 31u) : 0;      // rows 1..64
             for (u32 col = (u32)lane; col < sh.ry_iter; col += LZ_DP_LANES) {
@@ -515,7 +528,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             ct.prevLY = ct.LY;
             if (BOUNDS) lz_dp_update_lr(x, S, ct, J);
             q3 = LZ_PHASE_CLOCK();
-            if (SH::STAMP_WRAPS && ct.row > 1 && SH::stamp(ct.row) == 1u)          // the 16-bit stamps start over: none of the old ones may survive
+            if (BOUNDS && SH::STAMP_WRAPS && ct.row > 1 && SH::stamp(ct.row) == 1u)   // the 16-bit stamps start over: none of the old ones may survive
                 for (u32 k = 0; k < SH::RING; k++) sh.mk[k] = 0;
             if (BOUNDS) lz_dp_update_active(x, S, sh, ct, J, P.act_arena + J.act_off);
             q4 = LZ_PHASE_CLOCK();
@@ -586,7 +599,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH];
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 rx = LZ_RING(base + k);
-                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; vmk[k] = BOUNDS ? (u32)sh.mk[rx] : 0u; vbb[k] = sh.bb[rx];
+                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
                 }
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
@@ -620,7 +633,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH], vlk[LZ_DP_BATCH];
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 rx = LZ_RING(base + k);
-                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; vmk[k] = BOUNDS ? (u32)sh.mk[rx] : 0u; vbb[k] = sh.bb[rx];
+                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
                 }
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
