@@ -131,7 +131,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 #ifndef LZ_DP_WPE_FREE
 #define LZ_DP_WPE_FREE 7               // ... and seven of the problems without earlier alignments (no mask stamps: 22 KiB per DP)
 #endif
-template <bool NOTRIM, bool BOUNDS>
+template <bool NOTRIM, bool BOUNDS, bool REPLICATE>
 __global__ void __launch_bounds__(LZ_DP_LANES, BOUNDS ? LZ_DP_WPE : LZ_DP_WPE_FREE)
 k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
         const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
@@ -149,7 +149,7 @@ k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* _
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
     const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its snapshot, its query)
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM, BOUNDS>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS, REPLICATE>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
@@ -169,7 +169,7 @@ k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJ
     const LzDpJob J = jobs[j];
     const LzDpProblem pb = problems[J.problem];
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM, BOUNDS>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS, false>(x, sh, pb.S, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -263,8 +263,12 @@ struct HipDpExec : LzDpExecutor {
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.timer.begin("k_ydrop", c.stream);
-            hipLaunchKernelGGL(P.no_trim ? (bounds ? k_ydrop<true, true> : k_ydrop<true, false>) : (bounds ? k_ydrop<false, true> : k_ydrop<false, false>),
-                               dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
+            // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
+            // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
+            const bool repl = !bounds && n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
+            auto kern = P.no_trim ? (bounds ? k_ydrop<true, true, false> : repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>)
+                                  : (bounds ? k_ydrop<false, true, false> : repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
         c.timer.end(c.stream);

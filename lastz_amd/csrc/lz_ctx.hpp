@@ -55,6 +55,7 @@ struct SeqSlot {                    // a sequence resident in HBM
 struct LzCtx {
     bool inited = false;
     int  device = -1;
+    int  num_cus = 256;                 // compute units of the device (MI355X: 256)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // chunk pipeline: fill + histogram (stream) | scans (stream3) | partition + phase B (stream2)
     hipEvent_t ev_keys[LZ_SETS] = {}, ev_summ[LZ_SETS] = {}, ev_part[LZ_SETS] = {}, ev_extended[LZ_SETS] = {}, ev_init = nullptr;

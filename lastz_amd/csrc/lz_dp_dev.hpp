@@ -387,7 +387,8 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, SH& sh, LzDpCtl& c, 
 // BOUNDS: the problem has earlier alignments (bounds to follow, segments to mask).  Without any -- the first round of a
 // strand, where the longest DPs run -- the two routines of the row set-up, the mask stamps and their tests in the walks
 // drop out at compile time (7.2 k -> 6.7 k cycles per row with the routines skipped by a run-time test alone).
-template <bool NOTRIM, bool BOUNDS, class X, class SH>
+// REPLICATE (only without BOUNDS): see REPL below.
+template <bool NOTRIM, bool BOUNDS, bool REPLICATE, class X, class SH>
 LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
 {
@@ -411,7 +412,11 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     // copies cost nothing (the other three waves were waiting).  What the piece writes to LDS is the same from every
     // wave and each wave reads its own writes; only the list of active segments is updated in place, so this is for
     // problems without bounds.  Global stores stay with one wave.
-    constexpr bool REPL = !BOUNDS;
+    // The copies are not free when a CU is full: a SIMD issues one scalar instruction per four cycles whichever wave it
+    // comes from, and with seven DPs per CU every SIMD then carries seven copies of the piece instead of two (bench
+    // pair, both strands in one launch of 4468 DPs: 72.2 ms against 70.4 with one leading wave; one strand's 2300 DPs,
+    // whose launch lasts as long as its longest DP: 0.145 against 0.161 s for the two stages).  The launcher picks.
+    constexpr bool REPL = !BOUNDS && REPLICATE;
     LzDpCtl ct;                                                 // lane 0's (REPL: every wave's)
     // ---- set-up + row 0 (:3500-3605)
     auto setup = [&]() {

@@ -144,6 +144,7 @@ static int lz_init_locked(int device_index)
         if (n > 0) device_index %= n;
     }
     LZ_HIP(hipSetDevice(device_index));
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_index) == hipSuccess && prop.multiProcessorCount > 0) g_ctx.num_cus = prop.multiProcessorCount; }
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream3, hipStreamNonBlocking));

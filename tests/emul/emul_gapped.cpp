@@ -59,15 +59,15 @@ struct EmulExec : LzDpExecutor {
                 LzDpJob& J = jobs[k];
                 J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size(); J.act_off = 0;
                 CpuPhases x;
-                if (S.n_aligns) { if (no_trim) lz_dp_run<true, true>(x, sh, S, P, J, tab, &res[k]); else lz_dp_run<false, true>(x, sh, S, P, J, tab, &res[k]); }
-                else             { if (no_trim) lz_dp_run<true, false>(x, sh, S, P, J, tab, &res[k]); else lz_dp_run<false, false>(x, sh, S, P, J, tab, &res[k]); }
+                if (S.n_aligns) { if (no_trim) lz_dp_run<true, true, false>(x, sh, S, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(x, sh, S, P, J, tab, &res[k]); }
+                else             { if (no_trim) (k & 1 ? lz_dp_run<true, false, true, CpuPhases, LzDpShared> : lz_dp_run<true, false, false, CpuPhases, LzDpShared>)(x, sh, S, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, false, true, CpuPhases, LzDpShared> : lz_dp_run<false, false, false, CpuPhases, LzDpShared>)(x, sh, S, P, J, tab, &res[k]); }
                 if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
                     static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
                     static LzDpSharedWide shw;
                     shw.bind(ring.data());
                     CpuPhases xw;
-                    if (S.n_aligns) { if (no_trim) lz_dp_run<true, true>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, true>(xw, shw, S, P, J, tab, &res[k]); }
-                    else             { if (no_trim) lz_dp_run<true, false>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, false>(xw, shw, S, P, J, tab, &res[k]); }
+                    if (S.n_aligns) { if (no_trim) lz_dp_run<true, true, false>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(xw, shw, S, P, J, tab, &res[k]); }
+                    else             { if (no_trim) lz_dp_run<true, false, true>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, false, true>(xw, shw, S, P, J, tab, &res[k]); }
                     wide_runs++;
                 }
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
