@@ -265,7 +265,8 @@ struct HipDpExec : LzDpExecutor {
             c.timer.begin("k_ydrop", c.stream);
             // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
             // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
-            const bool repl = !bounds && n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
+            bool repl = !bounds && n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
+            if (const char* e = getenv("LZGPU_DP_REPL")) repl = !bounds && e[0] == '1';      // tests / A-B: force one or the other
             auto kern = P.no_trim ? (bounds ? k_ydrop<true, true, false> : repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>)
                                   : (bounds ? k_ydrop<false, true, false> : repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
             hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,

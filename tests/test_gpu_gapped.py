@@ -237,3 +237,23 @@ def test_paired_bases_limit(gpu):
     with pytest.raises(lzgpu.NotHandled) as e:
         _gpu_blocks(gpu, t, [q], max_paired_bases=1000)
     assert e.value.rc == 8
+
+
+@pytest.mark.parametrize("repl", ["0", "1"])
+@pytest.mark.parametrize("no_trim", [False, True])
+def test_both_forms_of_the_row_setup(gpu, repl, no_trim):
+    """k_ydrop<NOTRIM, false, REPLICATE>: problems without earlier alignments run the row set-up either on one leading
+    wave or replicated on all four (a launch-time choice by the number of DPs; LZGPU_DP_REPL forces it): same alignments"""
+    import test_oracle_vs_reference as T
+    t, q = T._option_pairs()["adversarial_piece"]
+    os.environ["LZGPU_DP_REPL"] = repl
+    try:
+        mine, _ = _gpu_blocks(gpu, t, [q], no_trim=no_trim)
+    finally:
+        del os.environ["LZGPU_DP_REPL"]
+    gold = "options_noytrim_adversarial_piece.lav" if no_trim else None
+    if gold:
+        assert mine == H.lav_blocks(os.path.join(H.GOLDEN, gold))
+    else:
+        sub, masked = H.scoring()
+        assert mine == T._oracle_blocks_with(t, q)
