@@ -64,6 +64,10 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         if ((__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave) f();     // a scalar branch: one wave, all its lanes
         __syncthreads();
     }
+    // traceback window: lane k of the leading wave holds link k (LzDpLane::tb_v)
+    __device__ __forceinline__ bool in_lead_wave(int lane) const { return (lane >> 6) == lead_wave; }
+    __device__ __forceinline__ u64 tb_ballot_diag() const { const u32 o = regs.tb_v & 3u; return __ballot(o != (u32)LZ_C_FROM_I && o != (u32)LZ_C_FROM_D); }
+    __device__ __forceinline__ u32 tb_link(u32 k) const { return (u32)__builtin_amdgcn_readlane((int)regs.tb_v, __builtin_amdgcn_readfirstlane((int)k)); }
     template <class F> __device__ __forceinline__ void every_wave(F&& f) { f(); }           // the serial piece on every wave's own copy of the state: no barrier
     __device__ __forceinline__ bool lead_here() const { return (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave; }
     __device__ __forceinline__ s32 uni(s32 v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -161,7 +161,6 @@ struct LzDpSharedBase {
     u32 r_first, r_last, r_ccol; s32 r_cmax;
     // traceback state
     u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
-    u8  tb_win[64];
     LzDpActive act[LZ_DP_ACT_LDS];        // the first active segments; the rest live in the job's HBM slot
 };
 template <class Ring> struct LzDpSharedT : LzDpSharedBase, Ring {};
@@ -189,6 +188,7 @@ struct LzDpLane {                       // per-lane values carried between the s
     s32 cand; u32 cand_col; s32 run_in; // best diagonal-won cell of the block; running best entering the block
     u32 first, last;                    // first / last live column of the block (0xFFFFFFFF: none)
     s32 bnd; u32 bnd_row, bnd_col, bnd_has;   // no_trim: the lane's best diagonal-won live cell on row M / column N, the latest on ties
+    u32 tb_v;                           // traceback: the link this lane of the leading wave fetched for the window
 };
 // Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
 // test harness); their semantics are fixed here:
@@ -748,34 +748,46 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         sh.tb_done = (ct.status != LZ_DP_OK) || !(ct.end1 >= 1 || ct.end2 > 0);
     });
     while (!sh.tb_done) {
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane >= LZ_DP_TBWIN) return;
-            const u32 k = (u32)lane;
+        // the 64 links along the diagonal below the current point, one per lane of the leading wave, kept in registers
+        x.phase([&](int lane, LzDpLane& r) {
+            if (!x.in_lead_wave(lane)) return;
+            const u32 k = (u32)lane & 63u;
             u32 v = 0xFFu;
             if (k <= sh.tb_row && k <= sh.tb_col) v = tb[(u32)(trow[sh.tb_row - k] + (sh.tb_col - k))];
-            sh.tb_win[k] = (u8)v;
+            r.tb_v = v;
         });
-        x.phase([&](int lane, LzDpLane&) {
-            if (lane != x.lead_lane()) return;
-            u32 row = sh.tb_row, col = sh.tb_col, prev_op = sh.tb_prev, n_ops = sh.tb_nops;
-            u32 run_op = sh.tb_run_op, run_len = sh.tb_run_len, status = ct.status;
-            for (u32 k = 0; k < LZ_DP_TBWIN; k++) {
-                if (!(row >= 1 || col > 0)) break;
-                const u32 link = sh.tb_win[k];
+        // The leading wave walks the window, all its lanes in lockstep on the same (scalar) state.  A run of diagonal
+        // links is taken in ONE step: once the previous op is diagonal a link's op is its low two bits, so the run's
+        // length is a count of trailing ones in a ballot -- the walk used to be one dependent LDS read and a dozen
+        // dependent instructions per link, on one lane (350 cycles per link; 8 % of a long DP's time).
+        x.leader([&]() {
+            u32 row = x.uni(sh.tb_row), col = x.uni(sh.tb_col), prev_op = x.uni(sh.tb_prev), n_ops = x.uni(sh.tb_nops);
+            u32 run_op = x.uni(sh.tb_run_op), run_len = x.uni(sh.tb_run_len), status = ct.status;
+            const u64 diag = x.tb_ballot_diag();                // bit k: (link k & 3) is neither C_FROM_I nor C_FROM_D
+            u32 k = 0;
+            while (k < LZ_DP_TBWIN && (row >= 1 || col > 0)) {
+                const u32 link = x.tb_link(k);
                 u32 op = link & 3u;
                 if (prev_op == LZ_C_FROM_I && (link & LZ_I_EXT)) op = LZ_C_FROM_I;
                 if (prev_op == LZ_C_FROM_D && (link & LZ_D_EXT)) op = LZ_C_FROM_D;
                 const u32 eop = (op == LZ_C_FROM_I) ? 1u : (op == LZ_C_FROM_D) ? 2u : 3u;
-                if (eop == run_op) run_len++;
+                u32 steps = 1;
+                if (eop == 3u) {                                // the links that follow, for as long as they are diagonal too
+                    const u64 rest = (k + 1u < 64u) ? (diag >> (k + 1u)) : 0ull;
+                    u32 more = (u32)__builtin_ctzll(~rest);     // (rest has zeros on top: never all ones)
+                    if (more > LZ_DP_TBWIN - 1u - k) more = LZ_DP_TBWIN - 1u - k;
+                    const u32 lim = row > col ? row : col;      // step j of the run is taken while j < max(row, col): the walk ends at the origin
+                    steps = 1u + more; if (steps > lim) steps = lim;
+                }
+                if (eop == run_op) run_len += steps;
                 else {
                     if (run_len) { if (n_ops >= J.ops_cap) { status = LZ_DP_OPS_SLOT; break; } ops[n_ops++] = run_op | (run_len << 2); }
-                    run_op = eop; run_len = 1;
+                    run_op = eop; run_len = steps;
                 }
                 prev_op = op;
-                if (op == LZ_C_FROM_I)      { col--; }
-                else if (op == LZ_C_FROM_D) { row--; }
-                else                        { row--; col--; continue; }       // still on the window's diagonal
-                break;                                                          // a gap: the window is stale
+                if (op == LZ_C_FROM_I)      { col--; break; }   // a gap: the window is stale
+                else if (op == LZ_C_FROM_D) { row--; break; }
+                row -= steps; col -= steps; k += steps;         // still on the window's diagonal
             }
             const bool fin = (status != LZ_DP_OK) || !(row >= 1 || col > 0);
             if (fin && status == LZ_DP_OK && run_len) {

@@ -14,6 +14,9 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
     template <class F> void phase(F&& f) { for (int l = 0; l < LZ_DP_LANES; l++) f(l, lanes[l]); }
     template <class F> void step(F&& f)  { for (int l = LZ_DP_LANES - 1; l >= 0; l--) f(l, lanes[l]); }   // no barrier on the GPU: any lane order must do
     template <class F> void leader(F&& f) { f(); }
+    bool in_lead_wave(int lane) const { return lane < 64; }
+    u64 tb_ballot_diag() const { u64 m = 0; for (int l = 0; l < 64; l++) { const u32 o = lanes[l].tb_v & 3u; if (o != (u32)LZ_C_FROM_I && o != (u32)LZ_C_FROM_D) m |= 1ull << l; } return m; }
+    u32 tb_link(u32 k) const { return lanes[k].tb_v; }
     template <class F> void every_wave(F&& f) { f(); }          // (one copy of the control state here)
     bool lead_here() const { return true; }
     int lead_lane() const { return 0; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # traceback window of 256 links against 64 (variant build)
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/s26
-for lib in "" tb64 "" tb64; do
+for lib in "" ""; do
   if [ -n "$lib" ]; then export LZGPU_LIB=$GRAFT_REPO_ROOT/lastz_amd/liblzgpu_$lib.so; else unset LZGPU_LIB; fi
   timeout 600 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli > gpurun_out/s26/b.json 2> gpurun_out/s26/b.err
   L="$lib" python - <<'PY'
