@@ -139,10 +139,17 @@ static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
     const u32 pos1 = m.pos1, pos2 = m.pos2, end1 = m.end1, end2 = m.end2;
     u32 rob = 0xFFFFFFFFu, rot = 0xFFFFFFFFu, lob = 0xFFFFFFFFu, lot = 0xFFFFFFFFu;
     s32 m_rob = -1, m_rot = -1, m_lob = -1, m_lot = -1, b_rob = -1, b_rot = -1, b_lob = -1, b_lot = -1;
-    for (size_t o = 0; o < S.obi.size(); o++) {
+    // The reference walks every alignment and skips those that do not overlap [pos1, end1] in the target.  obi is ordered by
+    // pos1 and obi_maxend[o] is the largest end1 of obi[0..o]: everything before the first o whose running maximum
+    // reaches pos1 ends before pos1, everything from the first alignment that starts after end1 on starts after it --
+    // the same alignments in the same order, without the quadratic walk (9 k alignments at the north star's size).
+    size_t o_lo = 0;
+    { size_t lo = 0, hi = S.obi_maxend.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.obi_maxend[mid] >= pos1) hi = mid; else lo = mid + 1; } o_lo = lo; }
+    for (size_t o = o_lo; o < S.obi.size(); o++) {
         const s32 ai = S.obi[o];
         const LzDpAlign& al = S.aligns[ai];
-        if (al.pos1 > end1 || al.end1 < pos1) continue;
+        if (al.pos1 > end1) break;
+        if (al.end1 < pos1) continue;
         s32 bp = -1, k; s32 x;
         for (k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= pos1) { bp = k; break; }
         if (bp >= 0 && S.segs[bp].b1 <= pos1) {
@@ -170,15 +177,16 @@ static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
 static void insert_align(LzHostSnapshot& S, s32 ai)
 {
     const LzDpAlign& m = S.aligns[ai];
-    size_t p = 0;
-    while (p < S.obi.size() && S.aligns[S.obi[p]].pos1 < m.pos1) p++;
+    // (the reference's linear walks to the first entry with pos1 >= m.pos1 / end1 <= m.end1, as binary searches)
+    size_t p;
+    { size_t lo = 0, hi = S.obi.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.obi[mid]].pos1 < m.pos1) lo = mid + 1; else hi = mid; } p = lo; }
     S.obi.insert(S.obi.begin() + p, ai);
-    p = 0;
-    while (p < S.oed.size() && S.aligns[S.oed[p]].end1 > m.end1) p++;
+    const size_t p_obi = p;
+    { size_t lo = 0, hi = S.oed.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.oed[mid]].end1 > m.end1) lo = mid + 1; else hi = mid; } p = lo; }
     S.oed.insert(S.oed.begin() + p, ai);
     S.obi_maxend.resize(S.obi.size());
-    u32 mx = 0;
-    for (size_t o = 0; o < S.obi.size(); o++) { const u32 e = S.aligns[S.obi[o]].end1; if (e > mx) mx = e; S.obi_maxend[o] = mx; }
+    u32 mx = p_obi ? S.obi_maxend[p_obi - 1] : 0u;               // the running maximum is unchanged in front of the new entry
+    for (size_t o = p_obi; o < S.obi.size(); o++) { const u32 e = S.aligns[S.obi[o]].end1; if (e > mx) mx = e; S.obi_maxend[o] = mx; }
 }
 
 // score_alignment, src/gapped_extend.c:5631-5675
@@ -459,9 +467,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
-            s32 below = -1, above = -1;
-            for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < a1) { below = (s32)o; break; }
-            for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > a1) { above = (s32)o; break; }
+            s32 below = -1, above = -1;                         // (first entry of oed that ends before a1 / of obi that starts after it)
+            { size_t lo = 0, hi = S.oed.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.oed[mid]].end1 >= a1) lo = mid + 1; else hi = mid; } if (lo < S.oed.size()) below = (s32)lo; }
+            { size_t lo = 0, hi = S.obi.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.obi[mid]].pos1 <= a1) lo = mid + 1; else hi = mid; } if (lo < S.obi.size()) above = (s32)lo; }
             // the partition holding the anchor bounds its extension, :1356-1372 / ydrop_align :2515-2531
             u32 low1, high1, low2, high2;
             if (!partition_limits(G.sep1, G.n_sep1, a1, G.tlen, low1, high1) || !partition_limits(G.sep2, G.n_sep2, a2, G.qlen, low2, high2)
