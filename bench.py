@@ -385,6 +385,10 @@ def run_single(a, torch, lib):
         with tempfile.TemporaryDirectory() as d:
             tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
             seqio.write_fasta(tf, [("target", target)]); seqio.write_fasta(qf, [("query", query)])
+            # ... and the driver clears what a process frees before it hands it out again: a process that starts while the
+            # ~60 GiB this one just let go of are being cleared waits for it in its first large hipMalloc (1.8 s seen).
+            # The leg measures a stand-alone run, so it starts on a device that has settled.
+            time.sleep(5.0)
             c0 = time.time()
             p = subprocess.run([gpu_bin, "t.fa", "q.fa", "--ydrop=9430"], capture_output=True, text=True, cwd=d)
             cw = time.time() - c0
