@@ -214,8 +214,9 @@ typedef struct lz_gapped_args {
     /* partitioned sequences ("file[multi]", src/sequences.h:240-267): the positions of the NUL bytes
        that bound the partitions, ascending -- partition i lies strictly between sep[i] and sep[i+1]
        (n partitions: n+1 entries) -- or NULL.  An anchor's extension stays inside the partition
-       holding it (src/gapped_extend.c:1356-1372).  A pair holding two identical partitions is
-       declined (the reference adds trivial alignments for those, :1191-1290).                      */
+       holding it (src/gapped_extend.c:1356-1372).  The trivial alignments the reference adds for
+       identical partitions (:1191-1290) are added here too; only inhibit_trivial's test by sequence
+       NAME (:1485-1545) is not: a result that holds a candidate for it returns LZGPU_NH_IDENTICAL. */
     const uint32_t* sep1;  uint32_t n_sep1;
     const uint32_t* sep2;  uint32_t n_sep2;
     /* identical sequences (identical_sequences, src/gapped_extend.c:1886-1933: same length, same bases

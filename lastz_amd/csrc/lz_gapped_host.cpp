@@ -328,21 +328,49 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 {
     out.clear(); out_ops.clear();
     memset(&st, 0, sizeof(st));
-    // identical_sequences (src/gapped_extend.c:1886-1933): dna_toupper() of the bytes equal, same strand flags
-    const bool identical = !G.sep1 && !G.sep2 && !G.strands_differ && G.tlen == G.qlen && same_bases(G.t, G.q, G.tlen);
-    // partitioned sequences: identical_partition_of_sequence / identical_partitioned_sequences (:1127-1147) make the
-    // reference add trivial alignments; any pair of (partition | whole sequence) with the same bases is declined
-    if (G.sep1 || G.sep2) {
-        for (u32 k = 0; k + 1 < G.n_sep1 || (!G.sep1 && k == 0); k++) {
-            const u32 lo1 = G.sep1 ? G.sep1[k] + 1 : 0, hi1 = G.sep1 ? G.sep1[k + 1] : G.tlen;
-            if (hi1 > G.tlen || lo1 > hi1) return LZGPU_ERR_ARG;
-            for (u32 m = 0; m + 1 < G.n_sep2 || (!G.sep2 && m == 0); m++) {
-                const u32 lo2 = G.sep2 ? G.sep2[m] + 1 : 0, hi2 = G.sep2 ? G.sep2[m + 1] : G.qlen;
-                if (hi2 > G.qlen || lo2 > hi2) return LZGPU_ERR_ARG;
-                if (hi1 - lo1 == hi2 - lo2 && hi1 > lo1 && same_bases(G.t + lo1, G.q + lo2, hi1 - lo1)) return LZGPU_NH_IDENTICAL;
+    // The trivial alignments the reference puts in front of the anchors (src/gapped_extend.c:1118-1290):
+    //  * neither sequence partitioned: the self-alignment when identical_sequences says so (:1886-1933: dna_toupper() of
+    //    the bytes equal, same strand flags);
+    //  * seq1 partitioned, seq2 not: ONE, for the first partition of seq1 that is seq2 (identical_partition_of_sequence,
+    //    :2034-2113);
+    //  * both partitioned: one per partition pair (k, k) when ALL pairs are identical (identical_partitioned_sequences,
+    //    :1952-1997).
+    // With inhibitTrivial and partitions but no such "partitioned triviality" the reference instead drops, at output time,
+    // alignments that cover a whole partition pair of equal NAME (delayedCheckForTrivial, :1485-1545): names do not cross
+    // this ABI, so a result that holds a candidate for that test is declined at the end (below).
+    struct Triv { u32 lo1, lo2, len; };
+    std::vector<Triv> triv;
+    bool delayed_check = false;
+    auto n_parts = [](const u32* sep, u32 n_sep) { return sep ? (n_sep ? n_sep - 1 : 0u) : 1u; };
+    auto part_of = [&](const u32* sep, u32 k, u32 whole, u32& lo, u32& hi) { if (sep) { lo = sep[k] + 1; hi = sep[k + 1]; } else { lo = 0; hi = whole; } };
+    if (G.sep1) for (u32 k = 0; k + 1 < G.n_sep1; k++) if (G.sep1[k + 1] > G.tlen || G.sep1[k] + 1 > G.sep1[k + 1]) return LZGPU_ERR_ARG;
+    if (G.sep2) for (u32 k = 0; k + 1 < G.n_sep2; k++) if (G.sep2[k + 1] > G.qlen || G.sep2[k] + 1 > G.sep2[k + 1]) return LZGPU_ERR_ARG;
+    if (!G.sep1 && !G.sep2) {
+        if (!G.strands_differ && G.tlen == G.qlen && G.tlen > 0 && same_bases(G.t, G.q, G.tlen)) triv.push_back({ 0u, 0u, G.tlen });
+    } else if (G.sep1 && !G.sep2) {
+        bool found = false;
+        if (!G.strands_differ)
+            for (u32 k = 0; k < n_parts(G.sep1, G.n_sep1) && !found; k++) {
+                u32 lo, hi; part_of(G.sep1, k, G.tlen, lo, hi);
+                if (hi - lo != G.qlen) continue;
+                if (G.qlen == 0) return LZGPU_NH_IDENTICAL;               // (an empty sequence "identical" to an empty partition: left to the reference)
+                if (same_bases(G.t + lo, G.q, G.qlen)) { triv.push_back({ lo, 0u, G.qlen }); found = true; }
             }
+        delayed_check = G.inhibit_trivial && !found;
+    } else if (G.sep1 && G.sep2) {
+        bool all = !G.strands_differ && n_parts(G.sep1, G.n_sep1) == n_parts(G.sep2, G.n_sep2);
+        for (u32 k = 0; all && k < n_parts(G.sep1, G.n_sep1); k++) {
+            u32 lo1, hi1, lo2, hi2; part_of(G.sep1, k, G.tlen, lo1, hi1); part_of(G.sep2, k, G.qlen, lo2, hi2);
+            if (hi1 - lo1 != hi2 - lo2 || !same_bases(G.t + lo1, G.q + lo2, hi1 - lo1)) all = false;
         }
-    }
+        if (all)
+            for (u32 k = 0; k < n_parts(G.sep1, G.n_sep1); k++) {
+                u32 lo1, hi1, lo2, hi2; part_of(G.sep1, k, G.tlen, lo1, hi1); part_of(G.sep2, k, G.qlen, lo2, hi2);
+                if (hi1 == lo1) return LZGPU_NH_IDENTICAL;                // (empty partitions: left to the reference)
+                triv.push_back({ lo1, lo2, hi1 - lo1 });
+            }
+        delayed_check = G.inhibit_trivial && !all;
+    } else delayed_check = G.inhibit_trivial;                             // (seq2 alone partitioned: no partitioned triviality, :1124-1147)
     if (G.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
 
     // LZGPU_HOSTPROF=1: where the host time of the stage goes
@@ -358,12 +386,12 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     LzHostSnapshot S;
     struct Info { s32 s; u32 beg1, beg2, end1, end2; std::vector<u32> script; bool trivial = false; };
     std::vector<Info> info;                                    // parallel to S.aligns
-    if (identical && G.tlen > 0) {
-        // the trivial self-alignment bounds every anchor from the start, :1152-1189 (one diagonal segment; its
-        // score saturates at bestPossibleScore and is raised to the threshold "so it won't be discarded")
+    for (const Triv& tv : triv) {
+        // a trivial alignment bounds every anchor from the start, :1152-1290 (one diagonal segment; its score saturates
+        // at bestPossibleScore and is raised to the threshold "so it won't be discarded")
         s32 sc = 0;
-        for (u32 i = 0; i < G.tlen; i++) {
-            u8 a = G.t[i], b = G.q[i];
+        for (u32 i = 0; i < tv.len; i++) {
+            u8 a = G.t[tv.lo1 + i], b = G.q[tv.lo2 + i];
             if (a >= 'a' && a <= 'z') a -= 32;
             if (b >= 'a' && b <= 'z') b -= 32;
             const s32 w = G.sub[(u32)a * 256 + b];
@@ -372,16 +400,16 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             else sc = 0x7FFFFFFF;
         }
         LzDpAlign m; memset(&m, 0, sizeof(m));
-        m.pos1 = m.pos2 = 0; m.end1 = m.end2 = G.tlen - 1;
-        m.first_seg = m.last_seg = 0;
+        m.pos1 = tv.lo1; m.pos2 = tv.lo2; m.end1 = tv.lo1 + tv.len - 1; m.end2 = tv.lo2 + tv.len - 1;
+        m.first_seg = m.last_seg = (s32)S.segs.size();
         m.left_align1 = m.right_align1 = m.left_align2 = m.right_align2 = -1;
         m.left_seg1 = m.right_seg1 = m.left_seg2 = m.right_seg2 = -1;
-        LzDpSeg g; g.b1 = g.b2 = 0; g.e1 = g.e2 = G.tlen - 1; g.type = LZ_DIAG_SEG;
+        LzDpSeg g; g.b1 = m.pos1; g.b2 = m.pos2; g.e1 = m.end1; g.e2 = m.end2; g.type = LZ_DIAG_SEG;
         S.segs.push_back(g); S.aligns.push_back(m);
-        Info in; in.s = sc < G.score_thresh ? G.score_thresh : sc; in.beg1 = in.beg2 = 1; in.end1 = in.end2 = G.tlen; in.trivial = true;
-        for (u32 left = G.tlen; left; ) { const u32 n = left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu; in.script.push_back((n << 2) | 3u); left -= n; }   // edit_script_sub
+        Info in; in.s = sc < G.score_thresh ? G.score_thresh : sc; in.beg1 = tv.lo1 + 1; in.beg2 = tv.lo2 + 1; in.end1 = tv.lo1 + tv.len; in.end2 = tv.lo2 + tv.len; in.trivial = true;
+        for (u32 left = tv.len; left; ) { const u32 n = left < 0x3FFFFFFFu ? left : 0x3FFFFFFFu; in.script.push_back((n << 2) | 3u); left -= n; }   // edit_script_sub
         info.push_back(std::move(in));
-        insert_align(S, 0);
+        insert_align(S, (s32)S.aligns.size() - 1);
     }
 
     const u32 W = G.window ? G.window : 1024;
@@ -597,6 +625,17 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, commit %.2f ms (neighbours %.2f, validity %.2f, build %.2f) (%u rounds)\n",
                       t_sort, t_window, t_exec, t_commit, t_c_lr, t_c_chk, t_c_build, (unsigned)st.rounds);
 
+    // ---- inhibitTrivial's test by sequence name (:1485-1545) cannot be made here: a result that holds a candidate for it
+    // (one diagonal piece covering a whole partition pair of equal length, base for base the same) goes back undone
+    if (delayed_check)
+        for (s32 ai : S.obi) {
+            const LzDpAlign& al = S.aligns[ai];
+            if (info[ai].s < G.score_thresh || al.first_seg != al.last_seg || S.segs[al.first_seg].type != LZ_DIAG_SEG) continue;
+            u32 lo1, hi1, lo2, hi2;
+            if (!partition_limits(G.sep1, G.n_sep1, al.pos1, G.tlen, lo1, hi1) || !partition_limits(G.sep2, G.n_sep2, al.pos2, G.qlen, lo2, hi2)) continue;
+            if (hi1 - lo1 != hi2 - lo2 || al.end1 + 1 - al.pos1 != hi1 - lo1) continue;
+            if (memcmp(G.t + al.pos1, G.q + al.pos2, al.end1 + 1 - al.pos1) == 0) return LZGPU_NH_IDENTICAL;
+        }
     // ---- output in increasing start order (orderBegInc), :1475-1566
     for (s32 ai : S.obi) {
         const Info& in = info[ai];

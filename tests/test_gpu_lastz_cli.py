@@ -192,9 +192,9 @@ def test_bench_pair_lav_fingerprint(tmp_path):
 
 
 @needs_bins
-@pytest.mark.parametrize("flags,notes", [(["--noytrim"], {"done on the GPU": 2}),
-                                         (["--allgappedbounds", "--gappedthresh=9000"], {"done on the GPU": 2}),
-                                         (["--querydepth=keep,nowarn:1.5"], {"done on the GPU": 2}),
+@pytest.mark.parametrize("flags,notes", [(["--noytrim"], {"done on the GPU": 1}),
+                                         (["--allgappedbounds", "--gappedthresh=9000"], {"done on the GPU": 1}),
+                                         (["--querydepth=keep,nowarn:1.5"], {"done on the GPU": 1}),
                                          (["--querydepth=keep,nowarn:0.02"], {"declined, reference path": 1})],
                          ids=["noytrim", "allgappedbounds", "querydepth-not-reached", "querydepth-reached"])
 def test_gapped_options_that_used_to_be_declined(sandbox, flags, notes):
@@ -212,3 +212,40 @@ def test_gapped_options_that_used_to_be_declined(sandbox, flags, notes):
         assert err.count("[lzgpu] gapped: " + how) >= n, err[-1500:]
     if "declined, reference path" not in notes:
         assert "[lzgpu] gapped: declined" not in err and "[lzgpu] gapped: reference path" not in err
+
+
+PART_CASES = {
+    # seq1 partitioned, seq2 = one of its partitions (identical_partition_of_sequence): one trivial alignment in front
+    "partition-of": (["pm.fa[multi]", "pq2.fa"], {"done on the GPU": 1}),
+    "partition-of-notrivial": (["pm.fa[multi]", "pq2.fa", "--notrivial"], {"done on the GPU": 1}),
+    # both partitioned, every pair (k, k) identical (identical_partitioned_sequences): one trivial alignment per pair
+    "all-pairs": (["pm.fa[multi]", "pm.fa[multi]"], {"done on the GPU": 1}),
+    "all-pairs-notrivial": (["pm.fa[multi]", "pm.fa[multi]", "--notrivial"], {"done on the GPU": 1}),
+    # both partitioned, the same sequences in another order: no partitioned triviality; without --notrivial nothing special
+    "reordered": (["pm.fa[multi]", "pr.fa[multi]"], {"done on the GPU": 1}),
+    # ... and with it the reference tells trivial alignments by sequence NAME at output time: a result that holds a
+    # candidate goes back to the reference's routine
+    "reordered-notrivial": (["pm.fa[multi]", "pr.fa[multi]", "--notrivial"], {"declined, reference path": 1}),
+}
+
+
+@needs_bins
+@pytest.mark.parametrize("case", list(PART_CASES))
+def test_identical_partitions(sandbox, case):
+    """the trivial alignments of partitioned sequences (src/gapped_extend.c:1118-1290, :1483-1545) on the device path
+    (round 2 declined any pair holding two identical partitions); byte-identical to the pristine binary"""
+    t, q = seqio.synth_pair(500_000, 400_000, seed=53)
+    parts = [("p1", t[:150_000]), ("p2", t[150_000:330_000]), ("p3", t[330_000:])]
+    seqio.write_fasta(sandbox / "pm.fa", parts)
+    seqio.write_fasta(sandbox / "pq2.fa", [("p2", parts[1][1])])
+    seqio.write_fasta(sandbox / "pr.fa", [parts[2], parts[0], parts[1]])
+    args, notes = PART_CASES[case]
+    args = args + ["--format=maf", "--ydrop=9430"]
+    a, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+    b, _ = run(REF_BIN, args, sandbox)
+    strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+    assert strip(a) == strip(b)
+    for how, n in notes.items():
+        assert err.count("[lzgpu] gapped: " + how) >= n, err[-1500:]
+    if "declined, reference path" not in notes:
+        assert "[lzgpu] gapped: declined" not in err
