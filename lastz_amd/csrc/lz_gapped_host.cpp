@@ -573,9 +573,20 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             const s64 lc0 = (s64)sp.a2 + 1 - (s64)rl.max_col - 2, lc1 = (s64)sp.a2 + 1 - (s64)rl.min_col + 2;
             const s64 rr0 = (s64)sp.a1 - 2, rr1 = (s64)sp.a1 + (s64)rr.max_row + 2;
             const s64 rc0 = (s64)sp.a2 + (s64)rr.min_col - 2, rc1 = (s64)sp.a2 + (s64)rr.max_col + 2;
+            // (only alignments that overlap the two rectangles' rows can touch them: obi is ordered by pos1 and obi_maxend is
+            // the running maximum of end1, so they are a stretch of obi found by bisection -- walking every alignment
+            // committed since the snapshot was quadratic, 10 ms per strand at the north star's size)
             auto touched_from = [&](size_t k0) {
-                for (size_t k = k0; k < S.aligns.size(); k++)
-                    if (align_touches(S, S.aligns[k], lr0, lr1, lc0, lc1) || align_touches(S, S.aligns[k], rr0, rr1, rc0, rc1)) return true;
+                const s64 row_lo = lr0 < rr0 ? lr0 : rr0, row_hi = lr1 > rr1 ? lr1 : rr1;
+                size_t lo = 0, hi = S.obi_maxend.size();
+                while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if ((s64)S.obi_maxend[mid] >= row_lo) hi = mid; else lo = mid + 1; }
+                for (size_t o = lo; o < S.obi.size(); o++) {
+                    const s32 ai = S.obi[o];
+                    const LzDpAlign& al = S.aligns[ai];
+                    if ((s64)al.pos1 > row_hi) break;
+                    if ((size_t)ai < k0) continue;
+                    if (align_touches(S, al, lr0, lr1, lc0, lc1) || align_touches(S, al, rr0, rr1, rc0, rc1)) return true;
+                }
                 return false;
             };
             // (a) same neighbour segments at the anchor as when it ran and nothing committed since
