@@ -76,8 +76,10 @@ int lzgpu_probe(void);
 /* lzgpu_init on a thread of its own (returns at once); any later call of the library waits for it to finish.  For a
  * host that has seconds of its own start-up work before it first needs the device (integration/lzgpu_shim.c). */
 void lzgpu_init_async(int device_index);
-/* Bind this process to one device (one process per GPU; LOCAL_RANK under torch.distributed). */
+/* Bind this process to one device (one process per GPU; LOCAL_RANK under torch.distributed).  The calling THREAD is
+ * bound as well, and so is every thread that later enters the library (HIP's current device is per host thread). */
 int lzgpu_init(int device_index);
+int lzgpu_device_index(void);              /* the device this process is bound to, -1 before lzgpu_init */
 void lzgpu_shutdown(void);
 void lzgpu_free(void* p);
 const char* lzgpu_last_error(void);

@@ -217,7 +217,15 @@ static void unit_marker (seq* seq2)
 	static int want = -1;
 	if (want < 0) { char* e = getenv ("LZGPU_UNIT_MARKERS");  want = ((e != NULL) && (e[0] == '1')); }
 	if (!want) return;
-	fprintf (stdout, "#lzgpu-unit %u %d\n", (seq2->contig >= 1)? seq2->contig : 1, ((seq2->revCompFlags & rcf_rev) != 0)? 1 : 0);
+	{
+	/* one marker per unit: a (contig, strand) that is searched more than once in a row (chore files) keeps its marker */
+	static u32 lastContig = 0;  static int lastRev = -1;
+	u32 contig = (seq2->contig >= 1)? seq2->contig : 1;
+	int rev    = ((seq2->revCompFlags & rcf_rev) != 0)? 1 : 0;
+	if ((contig == lastContig) && (rev == lastRev)) return;
+	lastContig = contig;  lastRev = rev;
+	fprintf (stdout, "#lzgpu-unit %u %d\n", contig, rev);
+	}
 	}
 
 static int fast_seed (seed* hitSeed, lz_seed_desc* sd)

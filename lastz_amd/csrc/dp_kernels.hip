@@ -15,6 +15,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <atomic>
+#include <system_error>
 #include "lz_ctx.hpp"
 #include "lz_host.hpp"
 #include "lz_gapped_host.hpp"
@@ -554,7 +556,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     LzCtx& c = lz_ctx();
     if (!args || !out || !n_out || !ops || !n_ops || n == 0) return lz_fail(LZGPU_ERR_ARG, "null argument");
     for (u32 k = 0; k < n; k++) { out[k] = nullptr; n_out[k] = 0; ops[k] = nullptr; n_ops[k] = 0; }
-    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    { int rc0 = lz_bind_thread(); if (rc0) return rc0; }
     if (!c.target.have_raw || c.target.host.size() != c.target.len || c.target.len != c.geom.tlen)
         return lz_fail(LZGPU_ERR_STATE, "no target on the device (lzgpu_table_prepare / lzgpu_target_upload)");
     const lz_gapped_args& a0 = args[0];
@@ -587,21 +589,42 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     ex.slot_tb = g_dp_slot_tb;
     { u32 nr = 0; for (int b = 0; b < 256; b++) if (rowc[b] >= nr) nr = (u32)rowc[b] + 1; ex.tab_rows = nr; }
 
-    DpRendezvous R(ex, (int)n);
+    // A bounded pool of host threads works through the problems (a tweener pass hands in tens of thousands of
+    // windows at the north star's size: one thread per problem would run into the process's thread limits, and a
+    // std::system_error must not leave an extern "C" function).  Each worker runs one problem at a time against the
+    // rendezvous and takes the next one when it is done, so `active` -- the number of submissions a launch waits
+    // for -- is the number of workers that still have a problem in hand.
+    static const u32 pool_cap = []() { const char* e = getenv("LZGPU_BATCH_THREADS"); const int v = e ? atoi(e) : 0; return (u32)(v > 0 ? v : 64); }();
+    const u32 want = std::min<u32>(n, pool_cap);
+    DpRendezvous R(ex, 0);
     std::vector<std::vector<lz_align>> al(n); std::vector<std::vector<u32>> op(n); std::vector<LzGappedStats> st(n); std::vector<int> rcs(n, 0);
     const int dev = c.device;
-    auto work = [&](u32 k) {
-        (void)hipSetDevice(dev);
-        DpClient cl(R, gp[k].qdp, gp[k].qlen);
-        cl.tdp = gp[k].tdp; cl.tlen = gp[k].tlen;
-        if (args[k].reduce) lzh_reduce_to_points(gp[k].G.t, gp[k].G.q, gp[k].G.sub, args[k].anchors, args[k].n_anchors);
-        rcs[k] = lzh_gapped_extend(gp[k].G, cl, args[k].anchors, args[k].n_anchors, al[k], op[k], st[k]);
+    std::atomic<u32> next_problem{0};
+    std::mutex start_m; std::condition_variable start_cv; bool started = false;
+    auto work = [&](bool own_thread) {
+        if (own_thread) {
+            (void)hipSetDevice(dev);
+            std::unique_lock<std::mutex> lk(start_m);
+            start_cv.wait(lk, [&] { return started; });
+        }
+        for (;;) {
+            const u32 k = next_problem.fetch_add(1);
+            if (k >= n) break;
+            DpClient cl(R, gp[k].qdp, gp[k].qlen);
+            cl.tdp = gp[k].tdp; cl.tlen = gp[k].tlen;
+            if (args[k].reduce) lzh_reduce_to_points(gp[k].G.t, gp[k].G.q, gp[k].G.sub, args[k].anchors, args[k].n_anchors);
+            rcs[k] = lzh_gapped_extend(gp[k].G, cl, args[k].anchors, args[k].n_anchors, al[k], op[k], st[k]);
+        }
         R.leave();
     };
     {
         std::vector<std::thread> th;
-        for (u32 k = 1; k < n; k++) th.emplace_back(work, k);
-        work(0);
+        try { for (u32 k = 1; k < want; k++) th.emplace_back(work, true); }
+        catch (const std::system_error&) { /* fewer workers than asked for: the ones that started do the work */ }
+        { std::lock_guard<std::mutex> lk(R.m); R.active = (int)th.size() + 1; }
+        { std::lock_guard<std::mutex> lk(start_m); started = true; }
+        start_cv.notify_all();
+        work(false);
         for (auto& t : th) t.join();
     }
     for (u32 k = 0; k < n; k++) {

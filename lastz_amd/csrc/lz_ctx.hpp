@@ -103,6 +103,7 @@ struct LzCtx {
 };
 
 LzCtx& lz_ctx();
+int lz_bind_thread();               // brings the context up if need be and binds the CALLING thread to its device (every entry point)
 int lz_fail(int code, const char* fmt, ...);
 #define LZ_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
     return lz_fail(LZGPU_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); } while (0)

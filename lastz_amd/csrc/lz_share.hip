@@ -67,7 +67,7 @@ static int table_share_impl(int rank, int world, const char* dir)
     if (world <= 1 && !getenv("LZGPU_SHARE_FORCE")) return 0;   // (LZGPU_SHARE_FORCE: a one-rank run still goes through the transport -- tests)
     if (world < 1) world = 1;
     if (rank < 0 || rank >= world || !dir) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_share: bad rank / world / directory");
-    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    { int rc = lz_bind_thread(); if (rc) return rc; }
     const std::string d(dir);
     const char* tr = getenv("LZGPU_SHARE_TRANSPORT");
     const bool by_file = tr && strcmp(tr, "file") == 0;
@@ -154,6 +154,7 @@ extern "C" int lzgpu_table_save(const char* path)
     if ((rc = lzgpu_table_geom(&g))) return rc;
     void* ptr[3]; uint64_t bytes[3];
     if ((rc = lzgpu_table_buffers(ptr, bytes))) return rc;
+    if ((rc = lz_bind_thread())) return rc;
     TabFileHead h; memset(&h, 0, sizeof(h));
     memcpy(h.magic, kMagic, 8); h.version = 1; h.endian = 0x01020304u; h.geom_bytes = (uint32_t)sizeof(g);
     for (int k = 0; k < 3; k++) h.bytes[k] = bytes[k];
@@ -181,7 +182,7 @@ extern "C" int lzgpu_table_load(const char* path)
 {
     LzCtx& c = lz_ctx();
     if (!path) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_load: null path");
-    if (!c.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    { int rc = lz_bind_thread(); if (rc) return rc; }
     FILE* f = fopen(path, "rb");
     if (!f) return lz_fail(LZGPU_ERR_ARG, "lzgpu_table_load: cannot open %s", path);
     TabFileHead h; lz_table_geom g;

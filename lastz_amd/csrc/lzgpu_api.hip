@@ -112,11 +112,18 @@ void KernelTimer::resolve()
 }
 void KernelTimer::reset() { resolve(); for (auto& x : ms) x = 0; for (auto& x : launches) x = 0; }
 
-static int require_init()
+// HIP's current device is a property of the HOST THREAD.  The context may have been brought up on another thread
+// (lzgpu_init_async's, or whichever thread called lzgpu_init first), so every entry point that touches the device
+// first binds the calling thread to the library's device: without it a rank r > 0 of a multi-GPU run would allocate
+// and copy on device 0 while its streams live on device r.  (hipSetDevice on the device that is already current
+// is a thread-local store.)
+int lz_bind_thread()
 {
     if (!g_ctx.inited) { int rc = lzgpu_init(-1); if (rc) return rc; }
+    LZ_HIP(hipSetDevice(g_ctx.device));
     return 0;
 }
+static int require_init() { return lz_bind_thread(); }
 
 extern "C" const char* lzgpu_last_error(void) { return g_ctx.last_error.c_str(); }
 
@@ -181,13 +188,17 @@ extern "C" int lzgpu_init(int device_index)
 {
     lz_wait_async();
     std::lock_guard<std::mutex> lk(g_init_mutex);
-    return lz_init_locked(device_index);
+    const int rc = lz_init_locked(device_index);
+    if (!rc) LZ_HIP(hipSetDevice(g_ctx.device));               // the caller's thread too (the context may be another thread's work)
+    return rc;
 }
+extern "C" int lzgpu_device_index(void) { return g_ctx.inited ? g_ctx.device : -1; }
 
 extern "C" void lzgpu_shutdown(void)
 {
     LzCtx& c = g_ctx;
     if (!c.inited) return;
+    (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     lz_phase_clocks_print();
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
@@ -356,7 +367,8 @@ extern "C" int lzgpu_table_rebuild(void)
 {
     LzCtx& c = g_ctx;
     if (!c.have_table) return lz_fail(LZGPU_ERR_STATE, "no position table");
-    int rc = lzk_table_build(c);
+    int rc = lz_bind_thread(); if (rc) return rc;
+    rc = lzk_table_build(c);
     if (!rc) c.geom.num_words = c.num_words;
     return rc;
 }
@@ -371,6 +383,7 @@ extern "C" int lzgpu_table_export(uint32_t* last, uint32_t* prev)
     u32 adj = c.geom.start - (c.geom.start % c.geom.step);
     u32 prev_entries = 1 + (c.geom.end - adj) / c.geom.step;       // src/pos_table.c:1065
     DevBuf dl, dp; int rc;
+    if ((rc = lz_bind_thread())) return rc;
     if (last && (rc = dl.ensure((size_t)nwords * 4))) return rc;
     if (prev && (rc = dp.ensure((size_t)prev_entries * 4))) { dl.release(); return rc; }
     rc = lzk_table_export(c, last ? dl.as<u32>() : nullptr, prev ? dp.as<u32>() : nullptr, prev_entries);
@@ -422,6 +435,7 @@ extern "C" int lzgpu_table_commit(void)
 {
     LzCtx& c = g_ctx;
     if (!c.target.have_raw || !c.wstart.p) return lz_fail(LZGPU_ERR_STATE, "no table buffers");
+    { int rc = lz_bind_thread(); if (rc) return rc; }
     // the entropy finish needs the target bytes on the host as well (the target itself does not
     // change between commits of the same geometry: copied back once)
     if (c.target.host.size() != c.geom.tlen) {

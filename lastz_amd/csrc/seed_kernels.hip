@@ -402,6 +402,148 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
     }
 }
 
+
+// ---- k_fill_hits2 (round 4): the same hits at the same places, the lists found through LDS instead of shuffles.
+// k_fill_hits lays the 64 lists of four positions end to end and lets every lane search the running totals for the list
+// holding its hit: 13 shuffles and two prefix sums per 64 hits, 150 VALU instructions per 64-hit trip for 16 bytes of
+// useful traffic per hit.  Here a wave takes its 64 sorted entries at once:
+//   1. every lane reads the CSR bounds of its position's probes (13 independent pairs of loads in flight per lane)
+//      and keeps the lengths; an exclusive wave scan of the lanes' totals places the positions' runs end to end
+//      (entry-major, probe order inside an entry = the reference's enumeration order inside a position);
+//   2. every list marks the cell of its first hit in own[] (its id); a prefix maximum over own[] -- ids grow along the
+//      concatenation -- leaves every cell with the id of the list that holds it: 16 marks and two passes over 128
+//      bytes per lane instead of a search per hit;
+//   3. lane t takes hits t, t + 64, ...: own[t] -> (list source - list start), (run's place in the key array - run
+//      start, pos2) from two small LDS tables -> one gather from wpos[], one key and one partition byte stored.  The
+//      stores of a wave are runs of consecutive keys (one run per position), as before.
+// A wave's LDS traffic is its own (no barrier: LDS operations of one wave execute in program order); concatenations
+// longer than LZ_F2_CAP hits (repeats) are taken in pieces; seeds with more than 16 probes in groups of 16.
+#ifndef LZ_F2_CAP
+#define LZ_F2_CAP   2560                             // hits per piece of a wave's concatenation: a multiple of 512; own[] 5 KiB + 4.5 KiB of tables per wave = four workgroups per CU (the 64 positions of a wave have 2.5 k hits on the 50 Mbp pair)
+#endif
+#define LZ_F2_WORDS (LZ_F2_CAP / 2 / 64)             // 32-bit words of own[] per lane
+static_assert(LZ_F2_CAP % 512 == 0, "whole 16-byte groups of own[] per lane");
+struct LzFill2Wave {
+    alignas(16) u32 own32[LZ_F2_CAP / 2];            // own[]: u16 list ids (1 + lane * 16 + probe), 0 = no list starts here
+    u32 lsrc[64 * LZ_FILL_GROUP];                    // list -> (first wpos index - start of the list in the concatenation)
+    uint2 ent[64];                                   // entry -> (place of its run in the key array - start of the run, pos2)
+};
+template <int CTRL, int ROWM, int BANKM>
+__device__ __forceinline__ u32 lz_dpp_u32(u32 ident, u32 src) { return (u32)__builtin_amdgcn_update_dpp((int)ident, (int)src, CTRL, ROWM, BANKM, false); }
+// inclusive wave scans (the classic row_shr 1,2,3 / 4 / 8 / row_bcast 15 / 31 sequence; unreached lanes get the identity)
+#define LZ_WAVE_SCAN_U32(v, x, OP)                                     \
+    v = OP(lz_dpp_u32<0x111, 0xf, 0xf>(0u, x), v);                     \
+    v = OP(lz_dpp_u32<0x112, 0xf, 0xf>(0u, x), v);                     \
+    v = OP(lz_dpp_u32<0x113, 0xf, 0xf>(0u, x), v);                     \
+    v = OP(lz_dpp_u32<0x114, 0xf, 0xe>(0u, v), v);                     \
+    v = OP(lz_dpp_u32<0x118, 0xf, 0xc>(0u, v), v);                     \
+    v = OP(lz_dpp_u32<0x142, 0xa, 0xf>(0u, v), v);                     \
+    v = OP(lz_dpp_u32<0x143, 0xc, 0xf>(0u, v), v);
+__device__ __forceinline__ u32 lz_uadd(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 lz_umax(u32 a, u32 b) { return a > b ? a : b; }
+__global__ void __launch_bounds__(LZ_TPB)
+k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
+             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
+             const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
+             u64 base, u64* __restrict__ keys, u8* __restrict__ bins)
+{
+    __shared__ LzFill2Wave shw[LZ_TPB / 64];
+    LzFill2Wave& sh = shw[threadIdx.x >> 6];
+    unsigned short* const own = reinterpret_cast<unsigned short*>(sh.own32);
+    const u32 lane = threadIdx.x & 63u;
+    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;           // one sorted entry per lane
+    u32 w_l = 0, i_l = 0; bool in = false;
+    if (j < n) { w_l = sk[j]; i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
+    if (!__ballot(in)) return;                                  // (wave-uniform: nothing of this chunk among the wave's entries)
+    const u32 dbase = in ? (u32)(off[i_l] - base) : 0u;         // (hit indices inside a chunk are 32-bit)
+    const u32 pos2 = lo + i_l + 1u;
+    u32 carry = 0;                                              // hits of the lane's position in the probe groups already done
+    for (int r = 0; r < sd.nprobes; r += LZ_FILL_GROUP) {       // uniform trip count
+        // ---- 1. bounds of the lane's lists
+        // (every load of the group is issued before the first is used: a lane without a probe reads word 0's bounds and
+        // drops them)
+        u32 la[LZ_FILL_GROUP], len[LZ_FILL_GROUP]; u32 total = 0;
+#pragma unroll
+        for (int p = 0; p < LZ_FILL_GROUP; p++) {
+            const bool on = in && r + p < sd.nprobes;
+            const u32 w = on ? (w_l ^ sd.probe_xor[(r + p) & (LZ_MAX_PROBES - 1)]) : 0u;
+            la[p] = wstart[w]; len[p] = wstart[w + 1];
+        }
+#pragma unroll
+        for (int p = 0; p < LZ_FILL_GROUP; p++) {
+            const bool on = in && r + p < sd.nprobes;
+            len[p] = on ? len[p] - la[p] : 0u; total += len[p];
+        }
+        u32 inc = total;
+        LZ_WAVE_SCAN_U32(inc, total, lz_uadd)
+        const u32 E = inc - total;                              // start of the lane's run in the wave's concatenation
+        const u32 T = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        {
+            u32 S = E;
+#pragma unroll
+            for (int p = 0; p < LZ_FILL_GROUP; p++) { sh.lsrc[lane * LZ_FILL_GROUP + p] = la[p] - S; S += len[p]; }
+        }
+        sh.ent[lane] = make_uint2(dbase + carry - E, pos2);
+        // ---- 2. + 3., a piece of LZ_F2_CAP hits at a time
+        for (u32 cs = 0; cs < T; cs += LZ_F2_CAP) {              // uniform
+            const u32 tc = (T - cs < (u32)LZ_F2_CAP) ? T - cs : (u32)LZ_F2_CAP;
+            uint4* const mine = reinterpret_cast<uint4*>(sh.own32 + lane * LZ_F2_WORDS);
+#pragma unroll
+            for (int k = 0; k < LZ_F2_WORDS / 4; k++) mine[k] = make_uint4(0u, 0u, 0u, 0u);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            {
+                u32 S = E;
+#pragma unroll
+                for (int p = 0; p < LZ_FILL_GROUP; p++) {
+                    const u32 l = len[p];
+                    if (l && S < cs + tc && S + l > cs) own[(S > cs ? S : cs) - cs] = (unsigned short)(1u + lane * LZ_FILL_GROUP + (u32)p);
+                    S += l;
+                }
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            // prefix maximum over own[]: the lane's 2 * LZ_F2_WORDS cells, then the lanes' last values, then the cells again
+            u32 wv[LZ_F2_WORDS];
+#pragma unroll
+            for (int k = 0; k < LZ_F2_WORDS / 4; k++) { const uint4 v = mine[k]; wv[4 * k] = v.x; wv[4 * k + 1] = v.y; wv[4 * k + 2] = v.z; wv[4 * k + 3] = v.w; }
+            u32 segmax = 0;
+#pragma unroll
+            for (int k = 0; k < LZ_F2_WORDS; k++) { const u32 m2 = lz_umax(wv[k] & 0xFFFFu, wv[k] >> 16); segmax = lz_umax(segmax, m2); }
+            u32 sinc = segmax;
+            LZ_WAVE_SCAN_U32(sinc, segmax, lz_umax)
+            u32 run = lz_dpp_u32<0x138, 0xf, 0xf>(0u, sinc);    // wave_shr:1: the maximum of the lanes below
+#pragma unroll
+            for (int k = 0; k < LZ_F2_WORDS; k++) {
+                const u32 a0 = lz_umax(wv[k] & 0xFFFFu, run), a1 = lz_umax(wv[k] >> 16, a0);
+                wv[k] = a0 | (a1 << 16); run = a1;
+            }
+#pragma unroll
+            for (int k = 0; k < LZ_F2_WORDS / 4; k++) mine[k] = make_uint4(wv[4 * k], wv[4 * k + 1], wv[4 * k + 2], wv[4 * k + 3]);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            // the hits of the piece, 64 per trip, consecutive lanes = consecutive hits; four trips' gathers in flight
+            // (a lane beyond the end of the piece reads the last hit again and stores nothing: no branch around the loads)
+            for (u32 tb = 0; tb < tc; tb += 256u) {
+                u32 p1[4], p2[4], dst[4]; bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 t0 = tb + 64u * (u32)k + lane;
+                    ok[k] = t0 < tc;
+                    const u32 t = ok[k] ? t0 : tc - 1u;
+                    const u32 list = (u32)own[t] - 1u;
+                    const u32 ls = sh.lsrc[list];
+                    const uint2 en = sh.ent[list / LZ_FILL_GROUP];
+                    const u32 tabs = cs + t;
+                    p1[k] = wpos[ls + tabs]; p2[k] = en.y; dst[k] = en.x + tabs;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (ok[k]) { const u64 kk = lz_hit_key(p1[k], p2[k]); keys[dst[k]] = kk; bins[dst[k]] = (u8)LZ_KEY_BIN(kk); }
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        }
+        carry += total;
+    }
+}
+
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st)
 {
     if (n == 0 || i1 <= i0) return 0;
@@ -409,9 +551,15 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
     if (c.n_owners > 1)
         hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
                            lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, c.n_owners, c.owner);
-    else
-        hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, 1u, 0u);
+    else {
+        static const bool old_fill = getenv("LZGPU_FILL_SHUFFLE") != nullptr;   // A/B aid: round 2's shuffle-search fill
+        if (old_fill)
+            hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
+                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, 1u, 0u);
+        else
+            hipLaunchKernelGGL(k_fill_hits2, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
+                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins);
+    }
     c.timer.end(st);
     LZ_HIP(hipGetLastError());
     return 0;
@@ -511,13 +659,20 @@ void lz_phase_clocks_print()
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof(h)) != hipSuccess) return;
     fprintf(stderr, "[lzgpu phase clocks] probe_part:");
     for (int k = 0; k < 10; k++) fprintf(stderr, " %llu", h[k]);
-    fprintf(stderr, "\n[lzgpu phase clocks] settle:");
-    for (int k = 16; k < 26; k++) fprintf(stderr, " %llu", h[k]);
+    fprintf(stderr, "\n[lzgpu phase clocks] settle (walker work, walker barrier wait, sorter work, sorter barrier wait; cycles summed over the 256 partitions):");
+    for (int k = 16; k < 20; k++) fprintf(stderr, " %llu", h[k]);
     fprintf(stderr, "\n");
 }
+// k_settle2: a walking wave's (slots 16, 17) and a sorting wave's (18, 19) cycles of work / of waiting at the tile barrier
+#define LZ_S2_CLK_BEGIN(who) unsigned long long _s2a = (who) ? __builtin_readcyclecounter() : 0ull, _s2b = 0ull
+#define LZ_S2_CLK_MID(who, slot) do { if (who) { _s2b = __builtin_readcyclecounter(); atomicAdd(&g_phase_clk[slot], _s2b - _s2a); } } while (0)
+#define LZ_S2_CLK_END(who, slot) do { if (who) atomicAdd(&g_phase_clk[slot], __builtin_readcyclecounter() - _s2b); } while (0)
 #else
 #define LZ_CLK_DECL
 #define LZ_CLK(slot)
+#define LZ_S2_CLK_BEGIN(who)
+#define LZ_S2_CLK_MID(who, slot)
+#define LZ_S2_CLK_END(who, slot)
 void lz_phase_clocks_print() {}
 #endif
 #ifndef LZ_PP_TPB
@@ -690,6 +845,15 @@ __device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzL
             rawl.tm = lz_load16(Q.tspx + oml); rawr.tm = lz_load16(Q.tspx + (oml + (mr - ml)));
             rawl.qm = lz_load16(Q.qsp + ((sql >> 3) - 14u)); rawr.qm = lz_load16(Q.qsp + (sqr >> 3));
         }
+    }
+#endif
+#if defined(LZ_EXP_DOUBLE_QUERY)        // timing experiment (results unchanged): the query windows fetched TWICE -- the slow-down is what
+    {                                   // the lanes' own query loads cost (would sharing them across lanes of equal pos2 pay?)
+        const u32 stl = pos1 - 1u + (u32)LZ_PAD2, str = pos1 + (u32)LZ_PAD2;
+        const u32 sql = stl - (u32)diag, sqr = str - (u32)diag;
+        const u8* q2b = Q.q2; asm volatile("" : "+v"(q2b));             // (laundered: not the same pointer to the compiler)
+        const LzVec16 xl = lz_load16(q2b + ((sql >> 2) - 15u)), xr = lz_load16(q2b + (sqr >> 2));
+        asm volatile("" :: "v"(xl.w[0]), "v"(xl.w[1]), "v"(xl.w[2]), "v"(xl.w[3]), "v"(xr.w[0]), "v"(xr.w[1]), "v"(xr.w[2]), "v"(xr.w[3]));
     }
 #endif
 #if defined(LZ_EXP_NO_LEFT_TARGET)      // timing experiments only (results are wrong): what the random target fetches cost
@@ -1166,12 +1330,15 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
         count_tile(1, cx, cslot);
         __syncthreads();
         for (u32 t = 0; t < ntiles; t++) {
+            LZ_S2_CLK_BEGIN(sw == 0 && lane == 0);
             if (t + 1 < ntiles) place_tile(t + 1, cx, cslot);
 #pragma unroll
             for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) cx[rr] = nx[rr];
             load_tile(t + 3, nx);                               // (past the last tile: no loads, "no record")
             if (t + 2 < ntiles) count_tile(t + 2, cx, cslot);
+            LZ_S2_CLK_MID(sw == 0 && lane == 0, 18);
             __syncthreads();
+            LZ_S2_CLK_END(sw == 0 && lane == 0, 19);
         }
         return;
     }
@@ -1185,6 +1352,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
     u32 dend = wl ? diag_end[h] : 0u;
     u64 n_ext = 0, n_bp = 0;
     for (u32 t = 0; t < ntiles; t++) {
+        LZ_S2_CLK_BEGIN(tid == 0);
         {
             const u64* const rec = sh.rec[t & 1u];
             u32 p = wl ? sh.lbeg[t & 1u][bucket] : 0u; const u32 end = wl ? p + sh.lcnt[t & 1u][bucket] : 0u;
@@ -1247,7 +1415,9 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
             }
             n_ext += ne; n_bp += nb;
         }
+        LZ_S2_CLK_MID(tid == 0, 16);
         __syncthreads();
+        LZ_S2_CLK_END(tid == 0, 17);
     }
     if (wl) diag_end[h] = dend;
     for (int o = 32; o > 0; o >>= 1) { n_ext += __shfl_down(n_ext, o); n_bp += __shfl_down(n_bp, o); }

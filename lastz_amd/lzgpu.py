@@ -63,7 +63,7 @@ ALIGN_DTYPE = np.dtype([("beg1", "<u4"), ("beg2", "<u4"), ("end1", "<u4"), ("end
                         ("s", "<i4"), ("script_len", "<u4"), ("script_off", "<u4")])
 
 # every symbol include/lzgpu.h declares (tests check that the library exports all of them)
-EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_init_async", "lzgpu_shutdown", "lzgpu_free",
+EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_device_index", "lzgpu_init_async", "lzgpu_shutdown", "lzgpu_free",
            "lzgpu_last_error", "lzgpu_table_prepare", "lzgpu_table_export", "lzgpu_table_rebuild", "lzgpu_table_num_words",
            "lzgpu_table_geom", "lzgpu_table_adopt", "lzgpu_table_buffers", "lzgpu_table_commit", "lzgpu_table_share", "lzgpu_table_save", "lzgpu_table_load", "lzgpu_device_copy",
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch", "lzgpu_window_search",

@@ -200,7 +200,11 @@ def split_marked(text):
     units = []
     for i, m in enumerate(ms):
         e = ms[i + 1].start() if i + 1 < len(ms) else len(text)
-        units.append(((int(m.group(1)), int(m.group(2))), text[m.end():e]))
+        key = (int(m.group(1)), int(m.group(2)))
+        if units and units[-1][0] == key:                          # the same unit marked twice in a row: one block
+            units[-1] = (key, units[-1][1] + text[m.end():e])
+        else:
+            units.append((key, text[m.end():e]))
     return text[:ms[0].start()], units
 
 
@@ -238,6 +242,11 @@ def check_supported(target, args):
     for a in args:
         if a.startswith("--output=") or a == "--markend":
             raise ValueError("lastz_amd.multi collects the ranks' standard output: %s is not supported" % a)
+        # searches that do not go through the seed_hit_search hook carry no unit plan (every rank would compute
+        # everything): anchors from a file, chore lists, quantum queries
+        if a.startswith("--segments=") or a.startswith("--chores=") or a.startswith("--anyornone") or "quantum" in a:
+            raise ValueError("lastz_amd.multi shards (query sequence, strand) units of the seed search: %s names work "
+                             "that does not come as such units; run it through a single lastz_gpu process" % a)
     tpath, tact = split_spec(target)
     if "[multi]" not in tact and os.path.exists(tpath):
         with open(tpath, "rb") as f:
