@@ -93,6 +93,28 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
         return xend;                                            // (wg[] is rewritten a row later, barriers in between)
     }
+    // The same scan for a row without masked cells (BOUNDS == false: cut is 0 in every lane).  Then K of a lane is gapE times
+    // its cells, the running sum of K over the lanes is a closed form -- cum(l) = gapE * min((l + 1) * cpl, width) -- and the
+    // composition of lanes 0..l applied to x0 is  max(x0, max_j (A_j + cum(j))) - cum(l):  ONE prefix maximum instead of
+    // the three-register map scan with its selects (95 -> 35 instructions of a wave that has its SIMD to itself, at five
+    // cycles each).  Same integers as the map algebra: no value comes near the ends of s32.
+    __device__ __forceinline__ s32 scan_gap_plain(LzDpSharedBase& sh, s32 x0, s32 gap_e, u32 cpl, u32 width)
+    {
+        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
+        const u32 ci = ((u32)lane + 1u) * cpl, ce = (u32)lane * cpl;
+        const s32 cum_incl = gap_e * (s32)(ci < width ? ci : width), cum_excl = gap_e * (s32)(ce < width ? ce : width);
+        const s32 x = regs.A + cum_incl;
+        s32 inc = x;
+        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
+        const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
+        if (wl == 63) sh.wc[w] = inc;                           // (wc[] is free here: scan_cand rewrites it behind the next barrier)
+        __syncthreads();
+        s32 pre = x0, all = x0;
+#pragma unroll
+        for (int j = 0; j < LZ_DP_WAVES; j++) { const s32 v = sh.wc[j]; if (j < w && v > pre) pre = v; if (v > all) all = v; }
+        regs.i_in = (ex > pre ? ex : pre) - cum_excl;
+        return all - gap_e * (s32)width;
+    }
     __device__ __forceinline__ void scan_cand(LzDpSharedBase& sh, s32 b0)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
@@ -216,6 +238,7 @@ struct HipDpExec : LzDpExecutor {
     explicit HipDpExec(LzCtx& ctx) : c(ctx) {}
 
     u64 wide_runs = 0;
+    double t_upload = 0, t_kernel = 0, t_ops = 0;               // LZGPU_HOSTPROF: host milliseconds in launch() / fetch_ops()
     u32 tab_rows = LZ_NCLASS;                                  // row classes of the score matrix in use (k_ydrop's dynamic LDS)
     const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
     bool bounds = true;                                         // some problem of the launch has earlier alignments (else: k_ydrop<.., false>)
@@ -228,6 +251,7 @@ struct HipDpExec : LzDpExecutor {
                std::vector<LzDpResult>& res, bool wide = false, bool by_estimate = false)
     {
         // slots: tb = slot bytes, rows = slot/16 entries, ops = slot/32 entries (all per DP)
+        const auto lt0 = std::chrono::steady_clock::now();
         const u64 n = ids.size();
         int rc;
         u64 tb_total = 0, row_total = 0, ops_total = 0;
@@ -260,6 +284,8 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.stream));
         P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
         P.act_arena = g_dp.act.as<LzDpActive>();
+        const auto lt1 = std::chrono::steady_clock::now();
+        t_upload += std::chrono::duration<double, std::milli>(lt1 - lt0).count();
         if (wide) {
             if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
             wide_runs += n;
@@ -285,6 +311,7 @@ struct HipDpExec : LzDpExecutor {
         LZ_HIP(hipMemcpyAsync(all.data(), g_dp.res.p, jobs.size() * sizeof(LzDpResult), hipMemcpyDeviceToHost, c.stream));
         LZ_HIP(hipStreamSynchronize(c.stream));
         c.timer.resolve();
+        t_kernel += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt1).count();
         for (u32 id : ids) res[id] = all[id];
         for (u32 id : ids)                                       // the DP that swept the most rows since the last reset (lzgpu_dp_longest)
             if (all[id].status == LZ_DP_OK && all[id].max_row > g_dp_longest[0]) {
@@ -323,6 +350,8 @@ struct HipDpExec : LzDpExecutor {
                   std::vector<std::vector<u32>>& ops)
     {
         // one block per job of THIS launch (ids), ops compacted back to back
+        const auto ft0 = std::chrono::steady_clock::now();
+        struct Acc { double& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } } acc{ t_ops, ft0 };
         std::vector<u64> off(jobs.size(), 0); u64 total = 0;
         std::vector<LzDpJob> sel; std::vector<LzDpResult> selr; std::vector<u64> seloff;
         for (u32 id : ids) { sel.push_back(jobs[id]); selr.push_back(res[id]); seloff.push_back(total); total += res[id].n_ops; }
@@ -570,6 +599,9 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     }
     if (a0.gap_extend <= 0) return LZGPU_NH_UNSUPPORTED;
     int rc;
+    static const bool hprof = getenv("LZGPU_HOSTPROF") != nullptr;
+    const auto hp0 = std::chrono::steady_clock::now();
+    auto hp_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - hp0).count(); };
     u8 rowc[256], colc[256]; s32 tab[LZ_NCLASS * LZ_NCLASS];
     if ((rc = lzh_score_classes(a0.sub, rowc, colc, tab))) return rc;
     std::vector<GappedProblem> gp(n);
@@ -594,6 +626,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     // std::system_error must not leave an extern "C" function).  Each worker runs one problem at a time against the
     // rendezvous and takes the next one when it is done, so `active` -- the number of submissions a launch waits
     // for -- is the number of workers that still have a problem in hand.
+    const double hp_prepared = hp_ms();
     static const u32 pool_cap = []() { const char* e = getenv("LZGPU_BATCH_THREADS"); const int v = e ? atoi(e) : 0; return (u32)(v > 0 ? v : 64); }();
     const u32 want = std::min<u32>(n, pool_cap);
     DpRendezvous R(ex, 0);
@@ -627,6 +660,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
         work(false);
         for (auto& t : th) t.join();
     }
+    const double hp_worked = hp_ms();
     for (u32 k = 0; k < n; k++) {
         c.counters.anchors_extended += st[k].anchors_extended; c.counters.dp_cells += st[k].dp_cells;
         c.counters.gapped_extensions += st[k].dp_runs; c.counters.truncated_extensions += st[k].truncated;
@@ -637,6 +671,8 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
             for (u32 j = 0; j <= k; j++) { free(out[j]); free(ops[j]); out[j] = nullptr; ops[j] = nullptr; n_out[j] = 0; n_ops[j] = 0; }
             return rc;
         }
+    if (hprof) fprintf(stderr, "[lzgpu hostprof] gapped batch of %u: prepare %.2f ms, problems %.2f ms, results %.2f ms; launches: %.2f ms upload, %.2f ms kernel + results back, %.2f ms edit ops back\n",
+                       n, hp_prepared, hp_worked - hp_prepared, hp_ms() - hp_worked, ex.t_upload, ex.t_kernel, ex.t_ops);
     return 0;
 }
 

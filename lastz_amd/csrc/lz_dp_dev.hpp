@@ -194,6 +194,8 @@ struct LzDpLane {                       // per-lane values carried between the s
 // test harness); their semantics are fixed here:
 //   X::scan_gap(sh,x0): r[l].i_in = (f_{l-1} o ... o f_0)(x0); returns (f_63 o ... o f_0)(x0)
 //                       composition g o f: A = g.cut ? g.A : max(g.A, f.A - g.K), K = f.K + g.K, cut = f.cut | g.cut
+//   X::scan_gap_plain(sh,x0,gapE,cpl,width): the same when no lane has cut set and every lane's K is gapE times its cells
+//                       (lane l: min(cpl, max(0, width - l * cpl)) cells) -- an executor may use the closed form of sum K
 //   X::scan_cand(sh,b0): r[l].run_in = max(b0, cand_0 .. cand_{l-1})
 //   X::reduce_row(..) : first live column (lowest lane having one), last live column (highest lane),
 //                       max cand and the column of the LAST lane attaining it; lane 0 fetches them in
@@ -627,7 +629,8 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             r.A = A; r.K = K; r.cut = cut;
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
-        i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
+        if constexpr (BOUNDS) i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
+        else                  i_last = x.uni(x.scan_gap_plain(sh, LZ_DP_NEGINF, gapE, cpl, RYi - LY0));    // (no masked cell: cut == 0, K = gapE per cell)
         const u64 tb_ = LZ_PHASE_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.step([&](int lane, LzDpLane& r) {

@@ -444,11 +444,15 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // will sweep (the anchors an alignment swallows line up along it).  Only the launch order uses it -- a launch
     // lasts as long as its longest DP, so the long ones should be among the first resident.
     std::vector<u32> ext_l, ext_r;
+    struct Member { u32 e, pos1, pos2; };                      // a deferred entry (index into entries) and its anchor
+    std::vector<std::vector<Member>> slot_members;             // the deferred entries found near a slot's selected anchor
+    std::vector<u8> covered;                                   // commit pass: the deferred entry lies on its slot's alignment (checked when that was committed)
     std::unordered_map<u32, u32> ext_of;                       // anchor index -> slot
     std::vector<std::pair<s64, s64>> slot_anchor;              // LZGPU_HOSTPROF: (diagonal, pos1) of a slot's selected anchor
     while (next < n_anchors) {
         // ---- speculation window against the current snapshot
         jobs.clear(); entries.clear(); fresh.clear(); ext_l.clear(); ext_r.clear(); ext_of.clear(); slot_anchor.clear();
+        for (auto& v : slot_members) v.clear();
         for (u32 t : touched) chosen_grid[t].clear();
         touched.clear();
         u32 insured = 0;
@@ -486,11 +490,12 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 // a loosely near anchor is usually on the selected anchor's alignment too, but when it is not it
                 // costs a whole extra round for one DP: a bounded number of them is speculated anyway
                 if (near == 1 && insured < INSURE) { insured++; near = 0; }
-                if (near) { entries.push_back({ j, false, near_slot }); continue; }
+                if (near) { slot_members[near_slot].push_back({ (u32)entries.size(), a1, a2 }); entries.push_back({ j, false, near_slot }); continue; }
             }
             ext_of[j] = (u32)ext_l.size();
             { const size_t gi = (size_t)(cell - cell_lo); if (chosen_grid[gi].empty()) touched.push_back((u32)gi); chosen_grid[gi].push_back({ dg, (s64)a1, (u32)ext_l.size() }); }
             ext_l.push_back(0); ext_r.push_back(0);
+            if (slot_members.size() < ext_l.size()) slot_members.emplace_back();
             if (prof) slot_anchor.push_back({ dg, (s64)a1 });
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
@@ -537,17 +542,16 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         // ---- commit in the reference's order
         bool cut = false;
         std::vector<s32> slot_align(ext_l.size(), -1);        // alignment committed for a selected anchor of this window
+        covered.assign(entries.size(), 0);
         for (size_t e = 0; e < entries.size(); e++) {
             const u32 aix = entries[e].anchor_ix;
             Neighbours nb;
+            // A deferred anchor nearly always lies on the alignment of the selected anchor it was found near, and "on an
+            // alignment" needs no more than one witness (:3953-4028): that was tested for all of a slot's deferred
+            // anchors at once when the slot's alignment was committed (below); one flag to read here.  (A deferred
+            // anchor has no cached DP: nothing to erase.)
+            if (covered[e]) continue;
             const double tq0 = prof ? now() : 0;
-            // A deferred anchor nearly always lies on the alignment of the selected anchor it was found near: that
-            // alignment first (one binary search); "on an alignment" needs no more than one witness (:3953-4028)
-            if (!entries[e].speculated && entries[e].near_slot < slot_align.size() && slot_align[entries[e].near_slot] >= 0
-                && on_alignment(S, S.aligns[slot_align[entries[e].near_slot]], anchors[aix].pos1, anchors[aix].pos2)) {
-                if (prof) t_c_lr += now() - tq0;
-                cache.erase(aix); continue;
-            }
             int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
             if (prof) t_c_lr += now() - tq0;
             if (ok < 0) return LZGPU_ERR_STATE;
@@ -622,7 +626,27 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             in.script.swap(b.script);
             info.push_back(std::move(in));
             insert_align(S, (s32)S.aligns.size() - 1);
-            if (entries[e].near_slot < slot_align.size()) slot_align[entries[e].near_slot] = (s32)S.aligns.size() - 1;
+            if (entries[e].near_slot < slot_align.size()) {
+                const u32 slot = entries[e].near_slot;
+                slot_align[slot] = (s32)S.aligns.size() - 1;
+                // the slot's deferred anchors that come later in the order: on this alignment?  One binary search each over
+                // the pieces of ONE alignment (hot in the cache), on a few threads when the alignment swallows thousands
+                const std::vector<Member>& mem = slot_members[slot];
+                const LzDpAlign& al = S.aligns.back();
+                auto check = [&](size_t lo, size_t hi) {
+                    for (size_t k = lo; k < hi; k++) {
+                        if (mem[k].e > e && on_alignment(S, al, mem[k].pos1, mem[k].pos2)) covered[mem[k].e] = 1;
+                    }
+                };
+                if (mem.size() < 4096) check(0, mem.size());
+                else {
+                    const size_t nt = std::min<size_t>(8, mem.size() / 2048);
+                    std::vector<std::thread> th;
+                    for (size_t t = 1; t < nt; t++) th.emplace_back(check, mem.size() * t / nt, mem.size() * (t + 1) / nt);
+                    check(0, mem.size() / nt);
+                    for (auto& x : th) x.join();
+                }
+            }
             if (G.max_paired_bases) {                          // count_paired_bases, :5695-5706; the limit test of :1441-1459
                 for (const LzDpSeg& g : segs) if (g.type == LZ_DIAG_SEG) paired_bases += (u64)g.e1 + 1 - g.b1;
                 if (paired_bases > G.max_paired_bases) return LZGPU_NH_PAIRED_LIMIT;

@@ -28,6 +28,25 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
         for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].i_in = x; LzDpGap f = { lanes[l].A, lanes[l].K, lanes[l].cut }; x = lz_dp_gap_apply(f, x); }
         return x;
     }
+    s32 scan_gap_plain(LzDpSharedBase& sh, s32 x0, s32 gap_e, u32 cpl, u32 width) {   // (checks what the GPU executor's closed form assumes)
+        for (int l = 0; l < LZ_DP_LANES; l++) {
+            const u32 lo = (u32)l * cpl, n = lo < width ? (width - lo < cpl ? width - lo : cpl) : 0u;
+            if (lanes[l].cut != 0 || lanes[l].K != gap_e * (s32)n) { fprintf(stderr, "emul: scan_gap_plain's precondition does not hold (lane %d)\n", l); abort(); }
+        }
+        // the closed form, lane by lane, against the map algebra
+        s32 pm = x0, x = x0;
+        for (int l = 0; l < LZ_DP_LANES; l++) {
+            const u32 ce = (u32)l * cpl, ci = ce + cpl;
+            const s32 cum_excl = gap_e * (s32)(ce < width ? ce : width), cum_incl = gap_e * (s32)(ci < width ? ci : width);
+            if (pm - cum_excl != x) { fprintf(stderr, "emul: closed form of the gap scan differs at lane %d\n", l); abort(); }
+            lanes[l].i_in = x;
+            LzDpGap f = { lanes[l].A, lanes[l].K, lanes[l].cut }; x = lz_dp_gap_apply(f, x);
+            const s32 b = lanes[l].A + cum_incl; if (b > pm) pm = b;
+        }
+        if (pm - gap_e * (s32)width != x) { fprintf(stderr, "emul: closed form of the gap scan differs at the end\n"); abort(); }
+        (void)sh;
+        return x;
+    }
     void scan_cand(LzDpSharedBase&, s32 b0) { s32 rb = b0; for (int l = 0; l < LZ_DP_LANES; l++) { lanes[l].run_in = rb; if (lanes[l].cand > rb) rb = lanes[l].cand; } }
     void reduce_row(LzDpSharedBase& sh) {
         u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu, ccol = 0; s32 cmax = LZ_DP_NEGINF - (1 << 24);
