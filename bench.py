@@ -48,7 +48,8 @@ def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
     (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, profiles/*pmc_fetch_write.csv).  Units and the
     gfx950 correction follow MI355X_MICROARCH.md: counters are in KiB; FETCH_SIZE under-reports wide
-    reads by 2x (uncalibrated for 16-byte gathers: reported as measured x2 = upper bound)."""
+    reads by 2x (uncalibrated for 16-byte gathers).  -> {"counted": FETCH + WRITE as counted, "corrected":
+    2 x FETCH + WRITE (an upper bound for gathers), "source"}"""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.csv")),
@@ -57,8 +58,9 @@ def pmc_traffic(kernel):
         for line in open(fn).read().split("\n")[1:]:
             f = line.split(",")
             if len(f) >= 4 and f[0] == kernel:
-                return (2.0 * float(f[2]) + float(f[3])) * 1024.0, os.path.basename(fn)
-    return None, None
+                fetch, write = float(f[2]) * 1024.0, float(f[3]) * 1024.0
+                return {"counted": fetch + write, "corrected": 2.0 * fetch + write, "source": os.path.basename(fn)}
+    return None
 
 
 def scoring():
@@ -194,7 +196,7 @@ def seed_roofline(prof, cnt, K, num_probes, dt):
     the diagEnd read / write per hit / extension (phase B = k_settle)."""
     W, Hh, E, X = (cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended"))
     V = num_probes
-    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_scan_hits": X, "k_settle": 4 * Hh + 4 * E}
+    alg = {"k_count_hits": W * (1 + 4 * V), "k_fill_hits": 4 * Hh, "k_scan_hits": X, "k_settle2": 4 * Hh + 4 * E}
     b_seed = W * (1 + 4 * V) + 8 * Hh + 4 * E + X
     kern_ms = {k: v["ms"] / K for k, v in prof.items()}
     dom = max((k for k in kern_ms if k in alg), key=lambda k: kern_ms[k], default=None)
@@ -203,9 +205,11 @@ def seed_roofline(prof, cnt, K, num_probes, dt):
     launches = prof[dom]["launches"] / K
     avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
     ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(dom)
+    tr = pmc_traffic(dom)
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": ach / HBM_PEAK_GBS, "traffic": tr["corrected"] if tr else None,
+            "traffic_counted": tr["counted"] if tr else None, "traffic_corrected": tr["corrected"] if tr else None,
+            "traffic_source": tr["source"] if tr else None,
             "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
             "launches_per_step": launches,
             # whole seed stage against the same roofline, on wall time
@@ -236,15 +240,21 @@ def lav_fingerprint(text):
     return hashlib.sha256("\n".join(lines).encode()).hexdigest()
 
 
-def setup_dist(torch):
+def setup_dist(torch, force_multi=False):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or force_multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                  # --force-multi: the N > 1 code path with one rank (the yardstick of the two-rank tests)
+            backend = os.environ.get("LZ_BENCH_BACKEND", "nccl")
+            rdv = tempfile.NamedTemporaryFile(prefix="lzbench_rdv_", delete=False); rdv.close(); os.unlink(rdv.name)
+            kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+            dist.init_process_group(backend, init_method="file://" + rdv.name, rank=0, world_size=1, **kw)
+            return world, rank, local, dist
         # "nccl" is RCCL on ROCm.  LZ_BENCH_BACKEND=gloo exists only to exercise this code path with two
         # ranks on a one-GPU box (RCCL refuses two ranks on the same device); it is not a measured mode.
         backend = os.environ.get("LZ_BENCH_BACKEND", "nccl")
@@ -277,10 +287,20 @@ def bcast_table(torch, dist, lib, rank, local):
     torch.cuda.synchronize()
 
 
-def run_single(a, torch, lib):
-    from lastz_amd import lzgpu, seqio
+def hsps_to_segs(lzgpu, hs, ident):
+    """HSPs as the reporter delivers them (end positions) -> anchor segments (src/segment.h: start positions)"""
+    sg = np.zeros(len(hs), dtype=lzgpu.SEG_DTYPE)
+    sg["pos1"] = hs["pos1"] - hs["length"]; sg["pos2"] = hs["pos2"] - hs["length"]
+    sg["length"] = hs["length"]; sg["s"] = hs["score"]; sg["id"] = ident
+    return sg
+
+
+def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
+    """B1 + B2 (+ the B3 leg) of one (target, query) pair on the resident library: warm-up, `steps` timed steps
+    (a step = table rebuild + both strands' searches), then optionally the gapped stage of the same pair.
+    -> (record, [HSPs of the + strand, of the - strand])"""
+    from lastz_amd import seqio
     sub, masked, ctb = scoring()
-    target, query = seqio.synth_pair(a.tlen, a.qlen, seed=1000)
     sd = lib.seed("1110100110010101111", 1)
     lib.table_prepare(target, sd, ctb)
     lib.query_upload(0, query)
@@ -292,162 +312,265 @@ def run_single(a, torch, lib):
         for slot in (0, 1):
             last[slot] = lib.seed_hit_search(masked, slot=slot)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lib.profile_enable(False)
     prof, cnt = lib.profile(), lib.counters()
-    K = max(a.steps, 1)
+    K = max(steps, 1)
+    tlen, qlen = len(target), len(query)
+    rec = {"ms_per_step": dt / K * 1e3, "value": (tlen / 1e9) / (dt / K), "steps": steps, "warmup": warmup,
+           "bp2_per_s": float(tlen) * float(qlen) * 2.0 / (dt / K), "scan_mode": lib.last_scan_mode(),
+           "hsps": int(len(last[0]) + len(last[1])),
+           "counters_per_step": {k: cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended")},
+           "kernel_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
+           "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt)}
+    # k_scan_hits against the same roofline whichever kernel dominates (the content legs: byte-code scans)
+    if "k_scan_hits" in prof and prof["k_scan_hits"]["launches"]:
+        ms = prof["k_scan_hits"]["ms"] / prof["k_scan_hits"]["launches"]
+        rec["k_scan_hits"] = {"avg_launch_ms": ms, "frac": cnt["bp_extended"] / prof["k_scan_hits"]["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if not do_gapped:
+        return rec, last
+    # ---- the gapped stage of the same pair (configs[2]: --ydrop=9430)
+    segs = [hsps_to_segs(lzgpu, h, rev) for rev, h in enumerate(last)]
+    probs = lambda: [dict(anchors=segs[slot].copy(), slot=slot, ydrop=9430) for slot in (0, 1)]
+    lib.gapped_extend_batch(sub, probs())                                       # warm-up (allocations)
+    # strand by strand, as the reference's host loop calls the stage (src/lastz.c:3401-3419) ...
+    torch.cuda.synchronize()
+    s0 = time.perf_counter()
+    for slot in (0, 1):
+        lib.gapped_extend(sub, segs[slot].copy(), slot=slot, ydrop=9430)
+    torch.cuda.synchronize()
+    sdt = time.perf_counter() - s0
+    # ... and both strands as one batch (lzgpu_gapped_extend_batch): the same alignments, the launches shared, so
+    # that one strand's launch does not sit out the other strand's longest DP
+    lib.profile_enable(True); lib.profile_reset(); lib.counters_reset(); lib.dp_longest(reset=True)
+    torch.cuda.synchronize()
+    g0 = time.perf_counter()
+    res = lib.gapped_extend_batch(sub, probs())
+    torch.cuda.synchronize()
+    gdt = time.perf_counter() - g0
+    nblocks = sum(len(al) for al, _ in res)
+    gpr, gc = lib.profile(), lib.counters()
+    lib.profile_enable(False)
+    kms = gpr.get("k_ydrop", {"ms": 0.0, "launches": 0})
+    dpl = lib.dp_longest()
+    rec["gapped"] = {"wall_s": gdt, "wall_s_strand_by_strand": sdt,
+                     "call": "lzgpu_gapped_extend_batch, both strands as one batch (wall_s); one lzgpu_gapped_extend per strand (wall_s_strand_by_strand)",
+                     "anchors": int(len(segs[0]) + len(segs[1])), "alignments": nblocks,
+                     "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"],
+                     "dp_cells_reference": gc["dp_cells"], "gcups_wall": gc["dp_cells"] / gdt / 1e9,
+                     "k_ydrop_ms": kms["ms"], "k_ydrop_launches": kms["launches"],
+                     # a launch lasts as long as its longest DP: shader cycles per row of that DP
+                     "longest_dp": {"rows": dpl["rows"], "cells": dpl["cells"],
+                                    "cycles_per_row": (dpl["sweep_ticks"] / dpl["rows"]) if dpl["rows"] else None,
+                                    "traceback_cycles": dpl["traceback_ticks"]},
+                     "kernel_ms": {k: v["ms"] for k, v in gpr.items() if v["ms"]},
+                     # algorithmic bytes of the DP, SURVEY 8(d): 1 traceback byte per visited cell
+                     "roofline": {"bound": "hbm", "kernel": "k_ydrop",
+                                  "achieved": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9) if kms["ms"] else None,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms["ms"] else None,
+                                  "traffic": None}}
+    return rec, last
+
+
+def cli_leg(seqio, target, query, runs=3):
+    """The lastz CLI bound to this library (reference host code + integration/lzgpu_shim.c + liblzgpu.so) on a pair:
+    wall clocks of `runs` + 1 stand-alone processes, back to back, and the LAV of the last one.  The first run starts
+    right after this process let go of its device buffers (the driver clears what a process frees before it hands it
+    out again: a run that starts meanwhile waits in its first large hipMalloc) -- reported on its own; `wall_s` is the
+    median of the others.  -> (record, LAV text or None)"""
+    gpu_bin = os.path.join(ROOT, "integration", "_build", "lastz_gpu")
+    if not os.path.exists(gpu_bin):
+        return None, None
+    with tempfile.TemporaryDirectory() as d:
+        tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
+        seqio.write_fasta(tf, [("target", target)]); seqio.write_fasta(qf, [("query", query)])
+        walls, out, rc = [], None, 0
+        for _ in range(runs + 1):
+            c0 = time.time()
+            p = subprocess.run([gpu_bin, "t.fa", "q.fa", "--ydrop=9430"], capture_output=True, text=True, cwd=d)
+            walls.append(round(time.time() - c0, 3))
+            rc = rc or p.returncode
+            out = p.stdout
+        rest = sorted(walls[1:])
+        rec = {"command": "integration/_build/lastz_gpu t.fa q.fa --ydrop=9430 (reference host code + integration/lzgpu_shim.c + liblzgpu.so)",
+               "wall_s": rest[len(rest) // 2], "wall_s_min": rest[0], "wall_s_first_after_free": walls[0], "runs_s": walls,
+               "wall_s_definition": "median of the %d runs that follow the first; the first starts right after this process freed its device buffers" % runs,
+               "rc": rc, "lav_blocks": out.count("\na {") if out else 0}
+        return rec, (out if rc == 0 else None)
+
+
+def golden(name, tlen, qlen):
+    gp = os.path.join(ROOT, "tests", "golden", name)
+    if os.path.exists(gp):
+        g = json.load(open(gp))
+        if g["tlen"] == tlen and g["qlen"] == qlen and g["seed"] == 1000:
+            return g
+    return None
+
+
+def soft_masked(seq, seed, frac=0.40, n_frac=0.005):
+    """`frac` of the bases in lower case (runs of 0.2 - 8 kbp: a soft-masked assembly) and `n_frac` in runs of N"""
+    rng = np.random.default_rng(seed)
+    s = seq.copy()
+    n = len(s)
+    mean = 4100.0
+    k = max(int(n * frac / mean), 1)
+    for st, ln in zip(rng.integers(0, n, k), rng.integers(200, 8000, k)):
+        s[st:st + ln] |= 0x20
+    k = max(int(n * n_frac / 2500.0), 1)
+    for st, ln in zip(rng.integers(0, n, k), rng.integers(100, 5000, k)):
+        s[st:st + ln] = ord("N")
+    return s
+
+
+def sparse_iupac(seq, seed, rate=1e-4):
+    rng = np.random.default_rng(seed)
+    s = seq.copy()
+    idx = rng.integers(0, len(s), max(int(len(s) * rate), 1))
+    s[idx] = np.frombuffer(b"RYKMSW", dtype=np.uint8)[rng.integers(0, 6, len(idx))]
+    return s
+
+
+def run_single(a, torch, lib):
+    from lastz_amd import lzgpu, seqio
+    target, query = seqio.synth_pair(a.tlen, a.qlen, seed=1000)
+    rec, last = measure_pair(torch, lib, lzgpu, target, query, a.steps, a.warmup, not a.no_gapped)
+    gold = golden("bench200m.sha.json" if a.north_star else "bench50m.sha.json", a.tlen, a.qlen)
 
     # ---- parity of the timed path's output: the reference's HSP list for this exact pair
     parity = {}
-    gold = None
-    gp = os.path.join(ROOT, "tests", "golden", "bench50m.sha.json")
-    if os.path.exists(gp):
-        g = json.load(open(gp))
-        if g["tlen"] == a.tlen and g["qlen"] == a.qlen and g["seed"] == 1000:
-            gold = g
     sha, nrows = hsp_rows_sha(last)
     parity["hsp_rows"] = nrows; parity["hsp_sha"] = sha
     parity["hsp_sha_ok"] = (sha == gold["hsp_sha"]) if gold else None
-    parity["reference"] = "tests/golden/bench50m.sha.json (pristine lastz 1.04.58 on this pair)" if gold else None
-
-    # ---- configs[2]: the gapped stage of the same pair
-    gapped = None
-    if not a.no_gapped:
-        segs = []
-        for rev, h in enumerate(last):
-            sg = np.zeros(len(h), dtype=lzgpu.SEG_DTYPE)
-            sg["pos1"] = h["pos1"] - h["length"]; sg["pos2"] = h["pos2"] - h["length"]
-            sg["length"] = h["length"]; sg["s"] = h["score"]; sg["id"] = rev
-            segs.append(sg)
-        probs = lambda: [dict(anchors=segs[slot].copy(), slot=slot, ydrop=9430) for slot in (0, 1)]
-        lib.gapped_extend_batch(sub, probs())                                       # warm-up (allocations)
-        # strand by strand, as the reference's host loop calls the stage (src/lastz.c:3401-3419) ...
-        torch.cuda.synchronize()
-        s0 = time.perf_counter()
-        for slot in (0, 1):
-            lib.gapped_extend(sub, segs[slot].copy(), slot=slot, ydrop=9430)
-        torch.cuda.synchronize()
-        sdt = time.perf_counter() - s0
-        # ... and both strands as one batch (lzgpu_gapped_extend_batch): the same alignments, the launches shared, so
-        # that one strand's launch does not sit out the other strand's longest DP
-        lib.profile_enable(True); lib.profile_reset(); lib.counters_reset(); lib.dp_longest(reset=True)
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        nblocks = sum(len(al) for al, _ in lib.gapped_extend_batch(sub, probs()))
-        torch.cuda.synchronize()
-        gdt = time.perf_counter() - g0
-        gpr, gc = lib.profile(), lib.counters()
-        lib.profile_enable(False)
-        kms = gpr.get("k_ydrop", {"ms": 0.0, "launches": 0})
-        dpl = lib.dp_longest()
-        gapped = {"workload": "BASELINE.json configs[2]: same pair, gapped stage, --ydrop=9430, both strands",
-                  "wall_s": gdt, "wall_s_strand_by_strand": sdt, "call": "lzgpu_gapped_extend_batch, both strands as one batch (wall_s); "
-                  "one lzgpu_gapped_extend per strand (wall_s_strand_by_strand)",
-                  "anchors": int(len(segs[0]) + len(segs[1])), "alignments": nblocks,
-                  "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"],
-                  "dp_cells_reference": gc["dp_cells"], "gcups_wall": gc["dp_cells"] / gdt / 1e9,
-                  "k_ydrop_ms": kms["ms"], "k_ydrop_launches": kms["launches"],
-                  # a launch lasts as long as its longest DP: shader cycles per row of that DP
-                  "longest_dp": {"rows": dpl["rows"], "cells": dpl["cells"],
-                                 "cycles_per_row": (dpl["sweep_ticks"] / dpl["rows"]) if dpl["rows"] else None,
-                                 "traceback_cycles": dpl["traceback_ticks"]},
-                  "kernel_ms": {k: v["ms"] for k, v in gpr.items()},
-                  # algorithmic bytes of the DP, SURVEY 8(d): 1 traceback byte per visited cell
-                  "roofline": {"bound": "hbm", "kernel": "k_ydrop",
-                               "achieved": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9) if kms["ms"] else None,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": (gc["dp_cells"] / (kms["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms["ms"] else None,
-                               "traffic": None}}
+    parity["reference"] = ("tests/golden/%s (pristine lastz 1.04.58 on this pair)" % ("bench200m.sha.json" if a.north_star else "bench50m.sha.json")) if gold else None
+    gapped = rec.get("gapped")
+    if gapped is not None:
+        gapped["workload"] = "BASELINE.json configs[2]: same pair, gapped stage, --ydrop=9430, both strands"
         if gold:
-            gapped["alignments_ok"] = (nblocks == gold["lav_blocks"])
-            # the reference's own gapped stage on this pair: the difference of its two whole runs (1 core each,
-            # measured where the golden fingerprints were made, tests/golden/make_bench_sha.py)
-            ref_s = gold["reference_wall_s"]["gapped"] - gold["reference_wall_s"]["nogapped"]
-            gapped["cpu_reference"] = {"stage_s_1core": ref_s, "gcups_1core": gc["dp_cells"] / ref_s / 1e9,
-                                       "speedup": ref_s / gdt, "source": "tests/golden/bench50m.sha.json (reference_wall_s gapped - nogapped)"}
+            gapped["alignments_ok"] = (gapped["alignments"] == gold["lav_blocks"])
 
-    # ---- the lastz CLI bound to this library on the same pair: wall clock + the LAV's fingerprint
+    # ---- the non-ideal content (scan modes 1 and 2) on the same pair, perf only (parity: tests/test_gpu_seed.py)
+    content = None
+    if not a.no_content and not a.north_star:
+        content = {}
+        for name, f in (("soft_masked_40pct_plus_N_runs", soft_masked), ("sparse_iupac_1e-4", sparse_iupac)):
+            r2, _ = measure_pair(torch, lib, lzgpu, f(target, 11), f(query, 12), 2, 1, False)
+            content[name] = {k: r2[k] for k in ("ms_per_step", "scan_mode", "hsps", "k_scan_hits")}
+            content[name]["kernel_ms_per_step"] = {k: round(v, 2) for k, v in r2["kernel_ms_per_step"].items() if v > 1.0}
+            content[name]["raw_hits_per_step"] = r2["counters_per_step"]["raw_hits"]
+
+    # ---- the size BASELINE.json's north_star quotes its targets on, inside the default line
+    ns = None
+    if not a.no_north_star and not a.north_star:
+        nt, nq = seqio.synth_pair(200_000_000, 200_000_000, seed=1000)
+        r3, l3 = measure_pair(torch, lib, lzgpu, nt, nq, 2, 1, True)
+        g2 = golden("bench200m.sha.json", len(nt), len(nq))
+        sha3, rows3 = hsp_rows_sha(l3)
+        ns = {"workload": "BASELINE.json north_star size: synthetic 200000000 bp target vs 200000000 bp query, 12-of-19 seed + 1 transition, both strands; "
+                          "1 warm-up + 2 timed steps of the seed stage, then the gapped stage (--ydrop=9430) as one batch",
+              **{k: r3[k] for k in ("ms_per_step", "value", "bp2_per_s", "hsps", "scan_mode", "counters_per_step", "kernel_ms_per_step", "roofline", "gapped")},
+              "parity": {"hsp_rows": rows3, "hsp_sha": sha3, "hsp_sha_ok": (sha3 == g2["hsp_sha"]) if g2 else None,
+                         "alignments_ok": (r3["gapped"]["alignments"] == g2["lav_blocks"]) if g2 else None,
+                         "reference": "tests/golden/bench200m.sha.json (pristine lastz 1.04.58 on this pair, tests/golden/make_bench200m_sha.py)" if g2 else
+                                      "no reference fingerprint committed for this pair: counts cross-checked between the library path and the bound CLI only"}}
+
+    # ---- the lastz CLI bound to this library on the same pair(s): wall clocks + the LAV's fingerprint.  The CLI is a
+    # process of its own: this one first lets go of its device buffers (~60 GiB of chunk buffers and DP arenas).
     cli = None
-    gpu_bin = os.path.join(ROOT, "integration", "_build", "lastz_gpu")
-    if not a.no_cli and os.path.exists(gpu_bin):
-        # the CLI is a process of its own: this one first lets go of its device buffers (~60 GiB of chunk buffers and
-        # DP arenas), as they would not be there in a stand-alone run -- a fresh process pays for device memory by
-        # the GiB when another process holds most of what the driver keeps ready
+    if not a.no_cli:
         lib.shutdown()
-        with tempfile.TemporaryDirectory() as d:
-            tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fa")
-            seqio.write_fasta(tf, [("target", target)]); seqio.write_fasta(qf, [("query", query)])
-            # ... and the driver clears what a process frees before it hands it out again: a process that starts while the
-            # ~60 GiB this one just let go of are being cleared waits for it in its first large hipMalloc (1.8 s seen).
-            # The leg measures a stand-alone run, so it starts on a device that has settled.
-            time.sleep(5.0)
-            c0 = time.time()
-            p = subprocess.run([gpu_bin, "t.fa", "q.fa", "--ydrop=9430"], capture_output=True, text=True, cwd=d)
-            cw = time.time() - c0
-            cli = {"command": "integration/_build/lastz_gpu t.fa q.fa --ydrop=9430 (reference host code + integration/lzgpu_shim.c + liblzgpu.so)",
-                   "wall_s": round(cw, 3), "rc": p.returncode, "lav_blocks": p.stdout.count("\na {")}
-            if p.returncode == 0:
-                fp = lav_fingerprint(p.stdout)
-                parity["lav_sha"] = fp
-                parity["lav_sha_ok"] = (fp == gold["lav_sha"]) if gold else None
-                if gold:
-                    cli["reference_wall_s_1core"] = gold["reference_wall_s"]["gapped"]
-                    cli["speedup_vs_reference_cli"] = gold["reference_wall_s"]["gapped"] / cw
+        cli, lav = cli_leg(seqio, target, query)
+        if cli is not None and lav is not None:
+            fp = lav_fingerprint(lav)
+            parity["lav_sha"] = fp
+            parity["lav_sha_ok"] = (fp == gold["lav_sha"]) if gold else None
+            if gold and "reference_wall_s" in gold:
+                cli["reference_wall_s_1core"] = gold["reference_wall_s"]["gapped"]
+                cli["speedup_vs_reference_cli"] = gold["reference_wall_s"]["gapped"] / cli["wall_s"]
+        if ns is not None:
+            c2, lav2 = cli_leg(seqio, nt, nq, runs=1)
+            if c2 is not None:
+                ns["cli"] = c2
+                if lav2 is not None:
+                    fp2 = lav_fingerprint(lav2)
+                    ns["parity"]["lav_sha"] = fp2
+                    ns["parity"]["lav_sha_ok"] = (fp2 == g2["lav_sha"]) if g2 else None
+                    ns["parity"]["cli_blocks_equal_library_alignments"] = (c2["lav_blocks"] == ns["gapped"]["alignments"])
 
-    W, Hh, E, X = (cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended"))
-    kern_ms = {k: v["ms"] / K for k, v in prof.items()}
-    roof = seed_roofline(prof, cnt, K, sd.num_probes, dt)
-    value = (a.tlen / 1e9) / (dt / K)
     out = {"metric": "Gbp-of-target aligned/sec (whole job, --nogapped HSP path, both strands)",
-           "value": value, "unit": "Gbp/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "value": rec["value"], "unit": "Gbp/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "s32", "data": "synthetic",
            "config": {"workload": ("BASELINE.json north_star size: " if a.north_star else "BASELINE.json configs[1]: ") +
                                   "synthetic %d bp target vs %d bp query, 12-of-19 seed + 1 transition, "
                                   "--nogapped, both strands" % (a.tlen, a.qlen),
-                      "tlen": a.tlen, "qlen": a.qlen, "scan_mode": lib.last_scan_mode()},
-           "bp2_per_s": float(a.tlen) * float(a.qlen) * 2.0 / (dt / K),
-           "hsps": int(len(last[0]) + len(last[1])),
-           "counters_per_step": {"words": W, "raw_hits": Hh, "extensions": E, "bp_extended": X},
-           "kernel_ms_per_step": kern_ms, "roofline": roof, "parity": parity}
+                      "tlen": a.tlen, "qlen": a.qlen, "scan_mode": rec["scan_mode"]},
+           "bp2_per_s": rec["bp2_per_s"], "hsps": rec["hsps"],
+           "counters_per_step": rec["counters_per_step"],
+           "kernel_ms_per_step": rec["kernel_ms_per_step"], "roofline": rec["roofline"], "parity": parity}
     if gapped is not None:
         out["gapped"] = gapped
     if cli is not None:
         out["cli"] = cli
+    if ns is not None:
+        out["north_star"] = ns
+    if content is not None:
+        out["content"] = content
     if not a.no_cpu_baseline:
         cb = cpu_baseline(target, query, a.qlen, min(a.cpu_sample, a.tlen, a.qlen), gapped=gapped is not None, whole_host=not a.no_whole_host)
         if gapped is not None and "gapped" in cb:
             gapped["cpu_baseline"] = cb.pop("gapped")
             gapped["speedup_vs_cpu_1core"] = gapped["gcups_wall"] / gapped["cpu_baseline"]["gcups"]
+            if ns is not None:
+                ns["gapped"]["speedup_vs_cpu_1core"] = ns["gapped"]["gcups_wall"] / gapped["cpu_baseline"]["gcups"]
         out["cpu_baseline"] = cb
-        out["speedup_vs_cpu_1core"] = value / cb["value"] if cb["value"] else None
+        out["speedup_vs_cpu_1core"] = rec["value"] / cb["value"] if cb["value"] else None
         if "whole_host" in cb:
-            out["speedup_vs_cpu_whole_host"] = value / cb["whole_host"]["value"]
+            out["speedup_vs_cpu_whole_host"] = rec["value"] / cb["whole_host"]["value"]
     print(json.dumps(out))
 
 
+def align_digest(al, op):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(al[["beg1", "beg2", "end1", "end2", "s"]]).tobytes()); h.update(np.ascontiguousarray(op).tobytes())
+    return h.hexdigest()
+
+
 def run_multi(a, torch, lib, world, rank, local, dist):
-    """configs[3] shape: one target, 15 query sequences x 2 strands LPT-sharded over the ranks, table broadcast once per job"""
+    """configs[3] shape: one target, 15 query sequences x 2 strands sharded over the ranks, table broadcast once per job;
+    every unit is searched (B2) and gapped-extended (B3), B3 of unit k beside B2 of unit k+1."""
+    import threading
     from lastz_amd import lzgpu, seqio, shard
-    _, masked, ctb = scoring()
+    sub, masked, ctb = scoring()
     tlen, nu, ulen = a.tlen_multi, a.q_units, a.q_unit_len
     target, _ = seqio.synth_pair(tlen, 64, seed=3000)
-    plan = shard.plan_units([ulen] * nu, world)
+    units_all = [(i, s) for i in range(nu) for s in (0, 1)]
+    # Fewer units than GPUs (one long query on a node): (sequence, strand) sharding leaves GPUs idle; B2 then shards
+    # INSIDE every unit by hashed-diagonal ownership (SURVEY 8e (1): every rank enumerates, each extends its buckets)
+    # and the unit's HSP parts meet on one rank for B3.  With more units than GPUs whole units win: the enumeration
+    # (count + fill, a quarter of a search) would be repeated on every rank.
+    owners = a.bucket_owners == "always" or (a.bucket_owners == "auto" and len(units_all) < world)
+    if owners:
+        plan = [[u for k, u in enumerate(units_all) if k % world == r] for r in range(world)]     # who runs B3 of a unit
+        mine_search = units_all
+    else:
+        plan = shard.plan_units([ulen] * nu, world)
+        mine_search = plan[rank]
     mine = plan[rank]
-    seqs = sorted({qi for qi, _ in mine})
     slots = {}
-    for qi in seqs:                                     # this rank's query sequences, homologous to the same target
+    for qi in sorted({qi for qi, _ in mine_search}):        # this rank's query sequences, homologous to the same target
         q = seqio.synth_query(target, ulen, seed=3100 + qi)
         for strand in (0, 1):
-            if (qi, strand) in mine:
+            if (qi, strand) in mine_search:
                 slot = 2 * qi + strand
                 lib.query_upload(slot, q if strand == 0 else seqio.revcomp(q))
                 slots[(qi, strand)] = slot
@@ -459,10 +582,14 @@ def run_multi(a, torch, lib, world, rank, local, dist):
     dist.broadcast_object_list(gb, src=0)
     if rank != 0:
         lib.table_adopt(lzgpu.TableGeom.from_buffer_copy(gb[0]))
+    if owners:
+        lib.set_bucket_owner(world, rank)
     dev = torch.device("cuda", local)
-    merged = [None]
-
-    phase = {"table_build": 0.0, "table_broadcast": 0.0, "search": 0.0, "gather_merge": 0.0}
+    use_cuda = dist.get_backend() == "nccl"
+    merged = [None]; aligned = [None]
+    phase = {"table_build": 0.0, "table_broadcast": 0.0, "search_and_gapped": 0.0, "gather_merge": 0.0}
+    busy = {"search_s": 0.0, "gapped_s": 0.0, "dp_cells": 0}
+    timeline = []
 
     def lap(name, t):
         torch.cuda.synchronize()
@@ -471,6 +598,7 @@ def run_multi(a, torch, lib, world, rank, local, dist):
 
     def step():
         t = time.perf_counter()
+        t_step = t
         if rank == 0:
             lib.table_rebuild()
         t = lap("table_build", t)
@@ -478,29 +606,67 @@ def run_multi(a, torch, lib, world, rank, local, dist):
         if rank != 0:
             lib.table_commit()
         t = lap("table_broadcast", t)
-        res = {u: lib.seed_hit_search(masked, slot=slots[u]) for u in mine}
-        t = lap("search", t)
-        # HSP lists to rank 0: sizes, then one padded gather; merged in file order, + before -
+        del timeline[:]
+        res, ali = {}, {}
+        worker = [None]
+
+        def gapped_of(u, hs):                               # second host thread, the library's B3 stream
+            g0 = time.perf_counter()
+            c0 = lib.counters()["dp_cells"]
+            (al, op), = lib.gapped_extend_batch(sub, [dict(anchors=hsps_to_segs(lzgpu, hs, u[1]), slot=slots[u], ydrop=9430)])
+            g1 = time.perf_counter()
+            ali[u] = (len(al), align_digest(al, op))
+            busy["gapped_s"] += g1 - g0; busy["dp_cells"] += lib.counters()["dp_cells"] - c0
+            timeline.append((list(u), "gapped", round(g0 - t_step, 4), round(g1 - t_step, 4)))
+
+        def start_gapped(u, hs):
+            if a.no_gapped:
+                return
+            if worker[0] is not None:
+                worker[0].join()
+            worker[0] = threading.Thread(target=gapped_of, args=(u, hs))
+            worker[0].start()
+
+        for u in mine_search:
+            s0 = time.perf_counter()
+            hs = lib.seed_hit_search(masked, slot=slots[u])
+            s1 = time.perf_counter()
+            busy["search_s"] += s1 - s0
+            timeline.append((list(u), "search", round(s0 - t_step, 4), round(s1 - t_step, 4)))
+            if owners:                                      # the unit's parts -> the rank that runs its B3, in discovery order
+                dst = units_all.index(u) % world
+                parts = [None] * world if rank == dst else None
+                dist.gather_object((hs, lib.last_hsp_order(len(hs))), parts, dst=dst)
+                if rank != dst:
+                    continue
+                hs = shard.merge_bucket_owners(parts)
+            res[u] = hs
+            start_gapped(u, hs)
+        if worker[0] is not None:
+            worker[0].join()
+        t = lap("search_and_gapped", t)
+        # HSP lists (and the alignments' digests) to rank 0: sizes, then one padded gather; merged in file order, + before -
         flat = np.concatenate([res[u].view(np.uint8) for u in mine]) if mine and sum(len(res[u]) for u in mine) else np.zeros(0, np.uint8)
         sizes = [None] * world
-        dist.all_gather_object(sizes, [(u, len(res[u])) for u in mine])
-        nbytes = [sum(n for _, n in s) * 16 for s in sizes]
+        dist.all_gather_object(sizes, [(u, len(res[u]), ali.get(u)) for u in mine])
+        nbytes = [sum(n for _, n, _ in s) * 16 for s in sizes]
         cap = max(max(nbytes), 16)
-        use_cuda = dist.get_backend() == "nccl"
         buf = torch.zeros(cap, dtype=torch.uint8, device=dev if use_cuda else "cpu")
         if len(flat):
             buf[:len(flat)] = torch.from_numpy(flat).to(buf.device)
         outl = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, outl, dst=0)
         if rank == 0:
-            per_rank = []
+            per_rank, per_rank_al = [], []
             for r in range(world):
                 arr = outl[r][:nbytes[r]].cpu().numpy().view(lzgpu.HSP_DTYPE)
-                d, o = {}, 0
-                for u, n in sizes[r]:
+                d, da, o = {}, {}, 0
+                for u, n, al in sizes[r]:
                     d[tuple(u)] = arr[o:o + n]; o += n
-                per_rank.append(d)
+                    da[tuple(u)] = al
+                per_rank.append(d); per_rank_al.append(da)
             merged[0] = shard.merge_units(per_rank)
+            aligned[0] = shard.merge_units(per_rank_al)
         lap("gather_merge", t)
 
     def fence():
@@ -523,6 +689,7 @@ def run_multi(a, torch, lib, world, rank, local, dist):
         step()
     for k in phase:
         phase[k] = 0.0
+    busy.update(search_s=0.0, gapped_s=0.0, dp_cells=0)
     lib.profile_enable(True); lib.profile_reset(); lib.counters_reset()
     fence()
     t0 = time.perf_counter()
@@ -530,12 +697,16 @@ def run_multi(a, torch, lib, world, rank, local, dist):
         step()
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if use_cuda else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     lib.profile_enable(False)
     prof, cnt = lib.profile(), lib.counters()
     K = steps_run
+    per_rank_busy = [None] * world
+    dist.all_gather_object(per_rank_busy, {"rank": rank, "units": len(mine_search), "search_s": busy["search_s"] / K, "gapped_s": busy["gapped_s"] / K,
+                                           "gapped_gcups": (busy["dp_cells"] / busy["gapped_s"] / 1e9) if busy["gapped_s"] else None,
+                                           "search_and_gapped_wall_s": phase["search_and_gapped"] / K})
     if rank == 0:
         kern_ms = {k: v["ms"] / K for k, v in prof.items()}
         cb = None
@@ -543,29 +714,50 @@ def run_multi(a, torch, lib, world, rank, local, dist):
             qs = seqio.synth_query(target[:a.cpu_sample], min(a.cpu_sample, ulen), seed=3100)
             cb = cpu_baseline(target, qs, a.qlen, min(a.cpu_sample, tlen, len(qs)), gapped=False, whole_host=False)
         nh = sum(len(v) for _, v in merged[0]) if merged[0] else 0
-        assert merged[0] is None or [u for u, _ in merged[0]] == [(i, s) for i in range(nu) for s in (0, 1)]
-        out = {"metric": "Gbp-of-target aligned/sec (whole job, --nogapped HSP path, both strands)",
+        assert merged[0] is None or [u for u, _ in merged[0]] == units_all
+        al_n = al_sha = None
+        if not a.no_gapped and aligned[0]:
+            assert [u for u, _ in aligned[0]] == units_all
+            al_n = sum(v[0] for _, v in aligned[0])
+            al_sha = hashlib.sha256("".join(v[1] for _, v in aligned[0]).encode()).hexdigest()
+        step_s = dt / K
+        tb = (phase["table_build"] + phase["table_broadcast"]) / K
+        out = {"metric": "Gbp-of-target aligned/sec (whole job, both strands: HSP search + gapped stage)" if not a.no_gapped else
+                         "Gbp-of-target aligned/sec (whole job, --nogapped HSP path, both strands)",
                # the N = 1 line quotes Gbp of target aligned per second against a query of a.qlen bases (configs[1]);
                # here the target meets nu * ulen bases of query per step: the same quantity, i.e. the same
                # bp^2 / s rate, is Tlen * (nu * ulen / a.qlen) / t -- so that the per-N values are comparable
-               "value": (tlen / 1e9) * (float(nu) * float(ulen) / float(a.qlen)) / (dt / K), "unit": "Gbp/s", "n_gpus": world,
+               "value": (tlen / 1e9) * (float(nu) * float(ulen) / float(a.qlen)) / step_s, "unit": "Gbp/s", "n_gpus": world,
                "steps": steps_run, "warmup": 1 + more_warm, "steps_requested": a.steps, "warmup_requested": a.warmup,
-               "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "s32", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[3] shape: synthetic %d bp target vs %d query sequences x %d bp "
-                                      "(= %d bp), 12-of-19 seed + 1 transition, --nogapped, both strands; a step = the whole job"
-                                      % (tlen, nu, ulen, nu * ulen),
+                                      "(= %d bp), 12-of-19 seed + 1 transition, both strands%s; a step = the whole job"
+                                      % (tlen, nu, ulen, nu * ulen, ", --nogapped" if a.no_gapped else ", gapped stage (--ydrop=9430) of every unit"),
                           "tlen": tlen, "q_units": nu, "q_unit_len": ulen,
                           "value_definition": "Gbp of target aligned per second, normalised to the %d bp query of the N = 1 line "
                                               "(configs[1]): Tlen * (total query bases / %d) / t; target_passes_gbp_per_s is the "
-                                              "unnormalised count (q_units * Tlen / t)" % (a.qlen, a.qlen),
-                          "parallelism": "%d (sequence x strand) units LPT-sharded over %d GPUs, position table built on rank 0 and "
-                                         "broadcast over RCCL/xGMI once per job, HSP lists gathered and merged on rank 0" % (2 * nu, world)},
-               "bp2_per_s": float(tlen) * float(nu) * float(ulen) * 2.0 / (dt / K),
-               "target_passes_gbp_per_s": float(nu) * (tlen / 1e9) / (dt / K),
-               "hsps_merged": int(nh), "units_per_rank": [len(p) for p in plan],
+                                              "unnormalised count (q_units * Tlen / t).  The N = 1 line's step is one 50 Mbp pair "
+                                              "without the gapped stage: a different workload, not the N = 1 point of this curve "
+                                              "(bench.py --gpus 1 --force-multi is)" % (a.qlen, a.qlen),
+                          "parallelism": ("%d (sequence x strand) units, every one searched by all %d GPUs (hashed-diagonal ownership inside "
+                                          "the unit), B3 of a unit on rank (unit index mod %d)" % (2 * nu, world, world)) if owners else
+                                         ("%d (sequence x strand) units LPT-sharded over %d GPUs" % (2 * nu, world)) +
+                                         ", position table built on rank 0 and broadcast over RCCL/xGMI once per job, the gapped stage of unit k on a "
+                                         "second stream beside the search of unit k+1, HSP lists + alignment digests merged on rank 0"},
+               "bp2_per_s": float(tlen) * float(nu) * float(ulen) * 2.0 / step_s,
+               "target_passes_gbp_per_s": float(nu) * (tlen / 1e9) / step_s,
+               "hsps_merged": int(nh), "alignments": al_n, "alignments_sha": al_sha,
+               "units_per_rank": [len(p) for p in plan], "bucket_owners": owners,
                # rank 0's clocks of the parts of a step (the table is built and broadcast once per job = once per step)
                "phase_ms_per_step_rank0": {k: v / K * 1e3 for k, v in phase.items()},
+               "table_build_and_broadcast_share_of_step": tb / step_s,
+               # B3 beside B2: a rank's wall for its units against the sum of the two stages' busy times
+               "per_rank": per_rank_busy,
+               "overlap": {"rank0_search_busy_s": per_rank_busy[0]["search_s"], "rank0_gapped_busy_s": per_rank_busy[0]["gapped_s"],
+                           "rank0_wall_s": per_rank_busy[0]["search_and_gapped_wall_s"],
+                           "rank0_wall_over_sum": per_rank_busy[0]["search_and_gapped_wall_s"] / max(per_rank_busy[0]["search_s"] + per_rank_busy[0]["gapped_s"], 1e-9)},
+               "timeline_rank0_last_step": sorted(timeline, key=lambda e: e[2]),
                "kernel_ms_per_step_rank0": kern_ms,
                "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt),      # rank 0's launches of the dominant kernel
                "cpu_baseline": cb}
@@ -582,14 +774,19 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-host", action="store_true", help="cpu_baseline: the 1-core figure only")
-    ap.add_argument("--no-gapped", action="store_true", help="skip the configs[2] leg (gapped stage of the same pair)")
-    ap.add_argument("--no-cli", action="store_true", help="skip the lastz CLI run (wall clock + LAV fingerprint)")
+    ap.add_argument("--no-gapped", action="store_true", help="skip the gapped stage (N = 1: the configs[2] leg; N > 1: B3 of every unit)")
+    ap.add_argument("--no-cli", action="store_true", help="skip the lastz CLI runs (wall clocks + LAV fingerprint)")
+    ap.add_argument("--no-north-star", action="store_true", help="N = 1: skip the 200 Mbp x 200 Mbp object of the default line")
+    ap.add_argument("--no-content", action="store_true", help="N = 1: skip the soft-masked / IUPAC legs (scan modes 1 and 2)")
     ap.add_argument("--gapped", action="store_true", help="(default now; kept for old command lines)")
     ap.add_argument("--tlen-multi", type=int, default=200_000_000, help="N > 1: target length (configs[3]: 200 Mbp)")
     ap.add_argument("--q-units", type=int, default=15, help="N > 1: query sequences (configs[3]: 15)")
     ap.add_argument("--q-unit-len", type=int, default=200_000_000, help="N > 1: bases per query sequence (configs[3]: 200 Mbp)")
-    ap.add_argument("--north-star", action="store_true", help="BASELINE.json north_star size: 200 Mbp x 200 Mbp, seed stage + Y-drop DP on one GPU "
-                                                              "(no CLI leg, 1-core CPU baseline only; the driver's line stays configs[1])")
+    ap.add_argument("--bucket-owners", choices=("auto", "always", "never"), default="auto",
+                    help="N > 1: shard B2 inside every unit by hashed-diagonal ownership (auto: when there are fewer units than GPUs)")
+    ap.add_argument("--force-multi", action="store_true", help="run the N > 1 code path with whatever WORLD_SIZE is (1 included)")
+    ap.add_argument("--north-star", action="store_true", help="the whole N = 1 line at BASELINE.json's north_star size (200 Mbp x 200 Mbp; no CLI leg, "
+                                                              "1-core CPU baseline only); the default line carries the same pair as its north_star object")
     ap.add_argument("--time-budget-s", type=float, default=1200.0, help="N > 1: warm-up + timed steps are cut to fit (a step is the whole 3 Gbp job)")
     a = ap.parse_args()
     if a.north_star:
@@ -597,16 +794,16 @@ def main():
         a.no_cli = True; a.no_whole_host = True
 
     import torch                                   # before liblzgpu.so: one HIP runtime per process
-    world, rank, local, dist = setup_dist(torch)
+    world, rank, local, dist = setup_dist(torch, a.force_multi)
     from lastz_amd import lzgpu
     lib = lzgpu.Lib()
     lib.init(local)
-    if world == 1:
+    if dist is None:
         run_single(a, torch, lib)
     else:
         run_multi(a, torch, lib, world, rank, local, dist)
     lib.shutdown()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

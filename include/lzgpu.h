@@ -14,7 +14,11 @@
  * single-threaded and non-reentrant, src/seed_search.c:364-365).  The library is a process-wide singleton: one device
  * context, one resident target / table, function-static caches (the last scoring matrix, compared by value, with its
  * class codes and look-up table; the DP arenas) -- calls from two threads, even on different sequences, are not
- * supported; the library itself uses a few worker threads for host-side loops and joins them before returning.
+ * supported, with ONE exception (round 4): B3 has its own stream, timer and buffers, so one thread may be inside
+ * lzgpu_gapped_extend / lzgpu_gapped_extend_batch on resident query slots while another is inside
+ * lzgpu_seed_hit_search / lzgpu_query_upload on OTHER slots -- the gapped stage of unit k beside the search of unit
+ * k+1 (bench.py --gpus N; src/lastz.c:3401-3419 runs them one after the other).  Two B2 calls or two B3 calls at once
+ * remain unsupported.  The library itself uses a few worker threads for host-side loops and joins them before returning.
  *
  * Return codes, every int-returning entry point:
  *     0   done, results are complete and bit-identical to the reference's

@@ -280,8 +280,8 @@ struct HipDpExec : LzDpExecutor {
         if ((rc = g_dp.jobs.ensure(jobs.size() * sizeof(LzDpJob)))) return rc;
         if ((rc = g_dp.ids.ensure(n * 4))) return rc;
         if ((rc = g_dp.res.ensure(jobs.size() * sizeof(LzDpResult)))) return rc;
-        LZ_HIP(hipMemcpyAsync(g_dp.jobs.p, jobs.data(), jobs.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
-        LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.jobs.p, jobs.data(), jobs.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.dp_stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.dp_stream));
         P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
         P.act_arena = g_dp.act.as<LzDpActive>();
         const auto lt1 = std::chrono::steady_clock::now();
@@ -289,28 +289,28 @@ struct HipDpExec : LzDpExecutor {
         if (wide) {
             if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
             wide_runs += n;
-            c.timer.begin("k_ydrop_wide", c.stream);
+            c.dp_timer.begin("k_ydrop_wide", c.dp_stream);
             hipLaunchKernelGGL(P.no_trim ? (bounds ? k_ydrop_wide<true, true> : k_ydrop_wide<true, false>) : (bounds ? k_ydrop_wide<false, true> : k_ydrop_wide<false, false>),
-                               dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.stream,
+                               dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
-            c.timer.begin("k_ydrop", c.stream);
+            c.dp_timer.begin("k_ydrop", c.dp_stream);
             // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
             // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
             bool repl = !bounds && n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
             if (const char* e = getenv("LZGPU_DP_REPL")) repl = !bounds && e[0] == '1';      // tests / A-B: force one or the other
             auto kern = P.no_trim ? (bounds ? k_ydrop<true, true, false> : repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>)
                                   : (bounds ? k_ydrop<false, true, false> : repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.stream,
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
-        c.timer.end(c.stream);
+        c.dp_timer.end(c.dp_stream);
         LZ_HIP(hipGetLastError());
         // results of this launch
         std::vector<LzDpResult> all(jobs.size());
-        LZ_HIP(hipMemcpyAsync(all.data(), g_dp.res.p, jobs.size() * sizeof(LzDpResult), hipMemcpyDeviceToHost, c.stream));
-        LZ_HIP(hipStreamSynchronize(c.stream));
-        c.timer.resolve();
+        LZ_HIP(hipMemcpyAsync(all.data(), g_dp.res.p, jobs.size() * sizeof(LzDpResult), hipMemcpyDeviceToHost, c.dp_stream));
+        LZ_HIP(hipStreamSynchronize(c.dp_stream));
+        c.dp_timer.resolve();
         t_kernel += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt1).count();
         for (u32 id : ids) res[id] = all[id];
         for (u32 id : ids)                                       // the DP that swept the most rows since the last reset (lzgpu_dp_longest)
@@ -362,15 +362,15 @@ struct HipDpExec : LzDpExecutor {
         if ((rc = dr.ensure(selr.size() * sizeof(LzDpResult)))) return rc;
         if ((rc = g_dp.ops_off.ensure(seloff.size() * 8))) return rc;
         if ((rc = g_dp.ops_out.ensure(total * 4))) return rc;
-        LZ_HIP(hipMemcpyAsync(dj.p, sel.data(), sel.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.stream));
-        LZ_HIP(hipMemcpyAsync(dr.p, selr.data(), selr.size() * sizeof(LzDpResult), hipMemcpyHostToDevice, c.stream));
-        LZ_HIP(hipMemcpyAsync(g_dp.ops_off.p, seloff.data(), seloff.size() * 8, hipMemcpyHostToDevice, c.stream));
-        hipLaunchKernelGGL(k_gather_ops, dim3((unsigned)sel.size()), dim3(256), 0, c.stream,
+        LZ_HIP(hipMemcpyAsync(dj.p, sel.data(), sel.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.dp_stream));
+        LZ_HIP(hipMemcpyAsync(dr.p, selr.data(), selr.size() * sizeof(LzDpResult), hipMemcpyHostToDevice, c.dp_stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.ops_off.p, seloff.data(), seloff.size() * 8, hipMemcpyHostToDevice, c.dp_stream));
+        hipLaunchKernelGGL(k_gather_ops, dim3((unsigned)sel.size()), dim3(256), 0, c.dp_stream,
                            dj.as<LzDpJob>(), dr.as<LzDpResult>(), g_dp.ops.as<u32>(), g_dp.ops_off.as<u64>(), g_dp.ops_out.as<u32>());
         LZ_HIP(hipGetLastError());
         std::vector<u32> flat(total);
-        LZ_HIP(hipMemcpyAsync(flat.data(), g_dp.ops_out.p, total * 4, hipMemcpyDeviceToHost, c.stream));
-        LZ_HIP(hipStreamSynchronize(c.stream));
+        LZ_HIP(hipMemcpyAsync(flat.data(), g_dp.ops_out.p, total * 4, hipMemcpyDeviceToHost, c.dp_stream));
+        LZ_HIP(hipStreamSynchronize(c.dp_stream));
         for (size_t k = 0; k < ids.size(); k++)
             ops[ids[k]].assign(flat.begin() + seloff[k], flat.begin() + seloff[k] + res[ids[k]].n_ops);
         return 0;
@@ -404,11 +404,11 @@ struct HipDpExec : LzDpExecutor {
             const LzHostSnapshot& snap = *items[p].snap;
             const size_t a = snap.aligns.size(), g = snap.segs.size();
             if (a) {
-                LZ_HIP(hipMemcpyAsync(g_dp.aligns.as<LzDpAlign>() + oa, snap.aligns.data(), a * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.stream));
-                LZ_HIP(hipMemcpyAsync(g_dp.obi.as<s32>() + oa, snap.obi.data(), a * 4, hipMemcpyHostToDevice, c.stream));
-                LZ_HIP(hipMemcpyAsync(g_dp.oed.as<s32>() + oa, snap.oed.data(), a * 4, hipMemcpyHostToDevice, c.stream));
+                LZ_HIP(hipMemcpyAsync(g_dp.aligns.as<LzDpAlign>() + oa, snap.aligns.data(), a * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.dp_stream));
+                LZ_HIP(hipMemcpyAsync(g_dp.obi.as<s32>() + oa, snap.obi.data(), a * 4, hipMemcpyHostToDevice, c.dp_stream));
+                LZ_HIP(hipMemcpyAsync(g_dp.oed.as<s32>() + oa, snap.oed.data(), a * 4, hipMemcpyHostToDevice, c.dp_stream));
             }
-            if (g) LZ_HIP(hipMemcpyAsync(g_dp.segs.as<LzDpSeg>() + os, snap.segs.data(), g * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.stream));
+            if (g) LZ_HIP(hipMemcpyAsync(g_dp.segs.as<LzDpSeg>() + os, snap.segs.data(), g * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.dp_stream));
             pb[p].S.aligns = g_dp.aligns.as<LzDpAlign>() + oa; pb[p].S.segs = g_dp.segs.as<LzDpSeg>() + os;
             pb[p].S.obi = g_dp.obi.as<s32>() + oa; pb[p].S.oed = g_dp.oed.as<s32>() + oa; pb[p].S.n_aligns = (s32)a;
             pb[p].qdp = items[p].qdp; pb[p].qlen = items[p].qlen; pb[p].tdp = items[p].tdp; pb[p].tlen = items[p].tlen;
@@ -416,7 +416,7 @@ struct HipDpExec : LzDpExecutor {
             for (LzDpJob J : *items[p].jobs) { J.problem = (u32)p; jobs.push_back(J); }
         }
         bounds = na != 0;
-        LZ_HIP(hipMemcpyAsync(g_dp.problems.p, pb.data(), pb.size() * sizeof(LzDpProblem), hipMemcpyHostToDevice, c.stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.problems.p, pb.data(), pb.size() * sizeof(LzDpProblem), hipMemcpyHostToDevice, c.dp_stream));
         problems_dev = g_dp.problems.as<LzDpProblem>();
         std::vector<LzDpResult> res(jobs.size());
         std::vector<std::vector<u32>> ops(jobs.size());
@@ -484,6 +484,7 @@ extern "C" int lzgpu_set_dp_window(uint32_t n) { g_dp_window = n; return 0; }
 
 int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len);     // lzgpu_api.hip
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256]);
+SeqSlot* lz_query_slot(LzCtx& c, int slot, bool create);
 
 // Several problems' DPs in the same launches without touching the per-problem host logic: every problem runs
 // lzh_gapped_extend on a thread of its own against a client executor; a client's run() hands the round's jobs to the
@@ -532,12 +533,11 @@ int gapped_prepare(LzCtx& c, const lz_gapped_args* a, int temp_slot, const u8 ro
     if (!a->sub || (!a->anchors && a->n_anchors)) return lz_fail(LZGPU_ERR_ARG, "null argument");
     if (a->query) {
         if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
-        gp.qs = &c.queries[temp_slot];
+        gp.qs = lz_query_slot(c, temp_slot, true);
         if ((rc = lz_slot_upload_public(c, *gp.qs, a->query, a->qlen))) return rc;
     } else {
-        auto it = c.queries.find(a->query_slot);
-        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
-        gp.qs = &it->second;
+        gp.qs = a->query_slot < 0 ? nullptr : lz_query_slot(c, a->query_slot, false);
+        if (!gp.qs) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
     }
     SeqSlot* qs = gp.qs;
     const u8* qhost = a->query ? a->query : qs->host.data();
@@ -547,12 +547,12 @@ int gapped_prepare(LzCtx& c, const lz_gapped_args* a, int temp_slot, const u8 ro
     // ---- DP class codes (UNmasked scoring, src/lastz.c:3421)
     if (encode_target) {
         if ((rc = c.target.dp.ensure((size_t)tfull + 2 * LZ_SEQ_PAD + 16))) return rc;
-        LZ_HIP(hipMemsetAsync(c.target.dp.p, 0, (size_t)tfull + 2 * LZ_SEQ_PAD + 16, c.stream));
+        LZ_HIP(hipMemsetAsync(c.target.dp.p, 0, (size_t)tfull + 2 * LZ_SEQ_PAD + 16, c.dp_stream));
         if ((rc = lz_encode_with(c, c.target.raw_base(), c.target.dp.as<u8>() + LZ_SEQ_PAD, tfull, rowc))) return rc;
     }
     if (!encoded.count(qs)) {
         if ((rc = qs->dp.ensure((size_t)qfull + 2 * LZ_SEQ_PAD + 16))) return rc;
-        LZ_HIP(hipMemsetAsync(qs->dp.p, 0, (size_t)qfull + 2 * LZ_SEQ_PAD + 16, c.stream));
+        LZ_HIP(hipMemsetAsync(qs->dp.p, 0, (size_t)qfull + 2 * LZ_SEQ_PAD + 16, c.dp_stream));
         if ((rc = lz_encode_with(c, qs->raw_base(), qs->dp.as<u8>() + LZ_SEQ_PAD, qfull, colc))) return rc;
         encoded[qs] = true;
     }
@@ -609,8 +609,8 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     for (u32 k = 0; k < n; k++)
         if ((rc = gapped_prepare(c, &args[k], -1 - (int)k, rowc, colc, k == 0, encoded, gp[k]))) return rc;
     if ((rc = g_dp.tab.ensure(sizeof(tab)))) return rc;
-    LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
+    LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.dp_stream));
+    LZ_HIP(hipStreamSynchronize(c.dp_stream));
 
     HipDpExec ex(c);
     ex.P.tdp = gp[0].tdp; ex.P.tlen = gp[0].tlen; ex.P.qdp = gp[0].qdp; ex.P.qlen = gp[0].qlen;

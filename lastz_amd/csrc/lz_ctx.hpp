@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "lz_common.hpp"
 #include "../../include/lzgpu.h"
 
@@ -58,6 +59,7 @@ struct LzCtx {
     int  num_cus = 256;                 // compute units of the device (MI355X: 256)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr, stream3 = nullptr;   // chunk pipeline: fill + histogram (stream) | scans (stream3) | partition + phase B (stream2)
+    hipStream_t dp_stream = nullptr;    // B3's own stream: lzgpu_gapped_extend(_batch) on one host thread may run beside lzgpu_seed_hit_search on another
     hipEvent_t ev_keys[LZ_SETS] = {}, ev_summ[LZ_SETS] = {}, ev_part[LZ_SETS] = {}, ev_extended[LZ_SETS] = {}, ev_init = nullptr;
     std::string last_error;
 
@@ -70,7 +72,8 @@ struct LzCtx {
     u64 num_words = 0;
 
     // ---- queries
-    std::map<int, SeqSlot> queries; // slot -> resident query; slot -1 = transient
+    std::map<int, SeqSlot> queries; // slot -> resident query; slot -1 = transient (map nodes are stable: a slot's address survives other slots' insertion)
+    std::mutex slots_m;             // guards look-ups / insertions in `queries` (B2 and B3 may run on two host threads)
 
     // ---- seed-search scratch
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
@@ -99,7 +102,8 @@ struct LzCtx {
     u64 hsp_capacity = (1ull << 24);
 
     lz_counters counters = {};
-    KernelTimer timer;
+    KernelTimer timer;              // B1 / B2 launches (the caller's thread)
+    KernelTimer dp_timer;           // B3 launches (dp_stream; possibly another host thread)
 };
 
 LzCtx& lz_ctx();
@@ -109,7 +113,7 @@ int lz_fail(int code, const char* fmt, ...);
     return lz_fail(LZGPU_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); } while (0)
 
 // ---- launchers implemented in seed_kernels.hip (all asynchronous on ctx.stream) ----
-int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev);
+int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev, hipStream_t st = nullptr, KernelTimer* timer = nullptr);   // defaults: c.stream, c.timer
 int lzk_pack_nibbles(LzCtx& c, const u8* code_alloc, u8* nib, size_t nbytes);
 int lzk_table_build(LzCtx& c);
 int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);

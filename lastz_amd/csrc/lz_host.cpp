@@ -156,14 +156,8 @@ int lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], 
     }
     s32 F[4][2];
     if (!lut_classes(M4, F)) return 0;
-    // special bytes end a scan: whatever they meet scores below -xDrop
-    for (int r = 0; r < 256; r++) {
-        if (!tocc[r]) continue;
-        for (int c = 0; c < 256; c++) {
-            if (!qocc[c]) continue;
-            if ((ctb[r] < 0 || ctb[c] < 0) && (s64)sub[256 * r + c] >= -(s64)xdrop) return 0;
-        }
-    }
+    // (special bytes -- everything outside A, C, G, T -- need no condition: a scan consumes one with its real score, from
+    // the class table, whether it ends the scan or not: lz_lut_window)
     // no four-base group loses more than xDrop over the (at most three) bases after a maximum set inside the group
     if (-3 * lo > xdrop) return 0;
     return 1;

@@ -155,6 +155,7 @@ static int lz_init_locked(int device_index)
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream2, hipStreamNonBlocking));
     LZ_HIP(hipStreamCreateWithFlags(&g_ctx.stream3, hipStreamNonBlocking));
+    LZ_HIP(hipStreamCreateWithFlags(&g_ctx.dp_stream, hipStreamNonBlocking));
     for (int k = 0; k < LZ_SETS; k++) {
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_keys[k], hipEventDisableTiming));
         LZ_HIP(hipEventCreateWithFlags(&g_ctx.ev_summ[k], hipEventDisableTiming));
@@ -203,7 +204,8 @@ extern "C" void lzgpu_shutdown(void)
     lz_phase_clocks_print();
     if (c.stream2) (void)hipStreamSynchronize(c.stream2);
     if (c.stream3) (void)hipStreamSynchronize(c.stream3);
-    c.timer.resolve();
+    if (c.dp_stream) (void)hipStreamSynchronize(c.dp_stream);
+    c.timer.resolve(); c.dp_timer.resolve();
     if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_words = 0; }
     DevBuf* bufs[] = { &c.target.raw, &c.target.code, &c.wstart, &c.wpos, &c.cnt, &c.off, &c.pk, &c.wiv, &c.wsk, &c.wsv, &c.lut,
                        &c.sort_tmp, &c.scan_tmp, &c.diag_end, &c.score_tab, &c.hsp_out, &c.hsp_count, &c.hsp_mc,
@@ -218,6 +220,8 @@ extern "C" void lzgpu_shutdown(void)
     (void)hipStreamDestroy(c.stream);
     if (c.stream2) (void)hipStreamDestroy(c.stream2);
     if (c.stream3) (void)hipStreamDestroy(c.stream3);
+    if (c.dp_stream) (void)hipStreamDestroy(c.dp_stream);
+    c.dp_stream = nullptr;
     for (int k = 0; k < LZ_SETS; k++) {
         hipEvent_t* ev[] = { &c.ev_keys[k], &c.ev_summ[k], &c.ev_part[k], &c.ev_extended[k] };
         for (hipEvent_t* e : ev) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
@@ -232,16 +236,17 @@ extern "C" void lzgpu_free(void* p) { free(p); }
 
 // ------------------------------------------------------------------------------ sequences
 
-static int slot_upload(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len, bool keep_host)
+static int slot_upload(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len, bool keep_host, hipStream_t st = nullptr)
 {
     int rc;
+    if (!st) st = c.stream;
     size_t total = (size_t)len + 2 * LZ_SEQ_PAD + 16;
     if ((rc = s.raw.ensure(total))) return rc;
     if ((rc = s.code.ensure(total))) return rc;
-    LZ_HIP(hipMemsetAsync(s.raw.p, 0, total, c.stream));
-    LZ_HIP(hipMemsetAsync(s.code.p, LZ_CODE_INVALID, total, c.stream));
-    if (len) LZ_HIP(hipMemcpyAsync(s.raw_base(), bytes, len, hipMemcpyHostToDevice, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
+    LZ_HIP(hipMemsetAsync(s.raw.p, 0, total, st));
+    LZ_HIP(hipMemsetAsync(s.code.p, LZ_CODE_INVALID, total, st));
+    if (len) LZ_HIP(hipMemcpyAsync(s.raw_base(), bytes, len, hipMemcpyHostToDevice, st));
+    LZ_HIP(hipStreamSynchronize(st));
     s.len = len; s.have_raw = true; s.code_key = 0;
     if (keep_host) s.host.assign(bytes, bytes + len); else s.host.clear();
     return 0;
@@ -304,15 +309,23 @@ void lz_dp_release_statics();                                  // dp_kernels.hip
 void lz_win_release_statics();                                // window_kernels.hip
 static void lz_release_statics() { g_cls_t.release(); g_cls_q.release(); g_cls_tmp.release(); lz_dp_release_statics(); lz_win_release_statics(); g_ctx.win_tab.release(); }
 
-int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len) { return slot_upload(c, s, bytes, len, false); }
+// (the two helpers of B3's set-up: on B3's stream, with B3's own class-table buffer and timer)
+int lz_slot_upload_public(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len) { return slot_upload(c, s, bytes, len, false, c.dp_stream); }
 int lz_encode_with(LzCtx& c, const u8* raw, u8* code, u32 len, const u8 cls[256])
 {
     int rc = g_cls_tmp.ensure(256); if (rc) return rc;
-    LZ_HIP(hipMemcpyAsync(g_cls_tmp.p, cls, 256, hipMemcpyHostToDevice, c.stream));
-    LZ_HIP(hipStreamSynchronize(c.stream));
-    if ((rc = lzk_encode(c, raw, code, len, g_cls_tmp.as<u8>()))) return rc;
-    LZ_HIP(hipStreamSynchronize(c.stream));
+    LZ_HIP(hipMemcpyAsync(g_cls_tmp.p, cls, 256, hipMemcpyHostToDevice, c.dp_stream));
+    LZ_HIP(hipStreamSynchronize(c.dp_stream));
+    if ((rc = lzk_encode(c, raw, code, len, g_cls_tmp.as<u8>(), c.dp_stream, &c.dp_timer))) return rc;
+    LZ_HIP(hipStreamSynchronize(c.dp_stream));
     return 0;
+}
+SeqSlot* lz_query_slot(LzCtx& c, int slot, bool create)
+{
+    std::lock_guard<std::mutex> lk(c.slots_m);
+    if (create) return &c.queries[slot];
+    auto it = c.queries.find(slot);
+    return it == c.queries.end() ? nullptr : &it->second;
 }
 
 extern "C" int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen)
@@ -320,7 +333,7 @@ extern "C" int lzgpu_query_upload(int32_t slot, const uint8_t* q, uint32_t qlen)
     int rc = require_init(); if (rc) return rc;
     if (slot < 0 || !q) return lz_fail(LZGPU_ERR_ARG, "bad query slot");
     if (qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
-    return slot_upload(g_ctx, g_ctx.queries[slot], q, qlen, true);
+    return slot_upload(g_ctx, *lz_query_slot(g_ctx, slot, true), q, qlen, true);
 }
 
 // ------------------------------------------------------------------------------ B1
@@ -486,12 +499,11 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     SeqSlot* qs;
     if (a->query) {
         if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
-        qs = &c.queries[-1];
+        qs = lz_query_slot(c, -1, true);
         if ((rc = slot_upload(c, *qs, a->query, a->qlen, false))) return rc;
     } else {
-        auto it = c.queries.find(a->query_slot);
-        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
-        qs = &it->second;
+        qs = a->query_slot < 0 ? nullptr : lz_query_slot(c, a->query_slot, false);
+        if (!qs) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
     }
     const u8* qhost = a->query ? a->query : qs->host.data();
     const u32 qlen = qs->len;
@@ -613,6 +625,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     LzLutParams Q;
     Q.t2 = c.target.two.as<u8>(); Q.q2 = qs->two.as<u8>(); Q.tsp = c.target.spc.as<u8>(); Q.qsp = qs->spc.as<u8>(); Q.xdrop = a->xdrop;
     Q.t2x = c.target.two_x.as<u8>(); Q.tspx = c.target.spc_x.as<u8>();
+    Q.tcode = P.tcode; Q.qcode = P.qcode;
     int mode = 2;
     if (a->extend) {
         s32 M4[16];
@@ -763,12 +776,11 @@ extern "C" int lzgpu_window_search(const lz_window_search_args* a, lz_hsp** out,
     SeqSlot* qs;
     if (a->query) {
         if (a->qlen >= 0x7FFFFFFFu) return LZGPU_NH_SIZE;
-        qs = &c.queries[-1];
+        qs = lz_query_slot(c, -1, true);
         if ((rc = slot_upload(c, *qs, a->query, a->qlen, false))) return rc;
     } else {
-        auto it = c.queries.find(a->query_slot);
-        if (it == c.queries.end() || a->query_slot < 0) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
-        qs = &it->second;
+        qs = a->query_slot < 0 ? nullptr : lz_query_slot(c, a->query_slot, false);
+        if (!qs) return lz_fail(LZGPU_ERR_ARG, "query slot %d is empty", a->query_slot);
     }
     for (u32 k = 0; k < a->n_windows; k++) {
         const lz_window& w = a->windows[k];
@@ -804,11 +816,13 @@ extern "C" int lzgpu_window_search(const lz_window_search_args* a, lz_hsp** out,
 
 extern "C" void lzgpu_counters_reset(void) { memset(&g_ctx.counters, 0, sizeof(g_ctx.counters)); }
 extern "C" int  lzgpu_counters_get(lz_counters* out) { if (!out) return LZGPU_ERR_ARG; *out = g_ctx.counters; return 0; }
-extern "C" void lzgpu_profile_enable(int enable) { g_ctx.timer.enabled = enable != 0; }
-extern "C" void lzgpu_profile_reset(void) { g_ctx.timer.reset(); }
+extern "C" void lzgpu_profile_enable(int enable) { g_ctx.timer.enabled = g_ctx.dp_timer.enabled = enable != 0; }
+extern "C" void lzgpu_profile_reset(void) { g_ctx.timer.reset(); g_ctx.dp_timer.reset(); }
 extern "C" int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* total_ms)
 {
-    KernelTimer& t = g_ctx.timer;
+    if (n >= (int)g_ctx.timer.names.size()) n -= (int)g_ctx.timer.names.size(); else if (n >= 0) n += 0x40000000;   // the seed stage's kernels first, then B3's
+    KernelTimer& t = n >= 0x40000000 ? g_ctx.timer : g_ctx.dp_timer;
+    n &= 0x3FFFFFFF;
     if (n < 0 || n >= (int)t.names.size()) return 1;
     if (name) *name = t.names[n].c_str();
     if (launches) *launches = t.launches[n];

@@ -59,14 +59,16 @@ int lzk_pack_nibbles(LzCtx& c, const u8* code_alloc, u8* nib, size_t nbytes)
     return 0;
 }
 
-int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev)
+int lzk_encode(LzCtx& c, const u8* raw, u8* code, u32 len, const u8* cls256_dev, hipStream_t st, KernelTimer* timer)
 {
     if (len == 0) return 0;
+    if (!st) st = c.stream;
+    if (!timer) timer = &c.timer;
     u32 nvec = (len + 15u) >> 4;
     u32 blocks = (nvec + LZ_TPB - 1) / LZ_TPB; if (blocks > 4096) blocks = 4096;
-    c.timer.begin("k_encode", c.stream);
-    hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(LZ_TPB), 0, c.stream, raw, code, len, cls256_dev);
-    c.timer.end(c.stream);
+    timer->begin("k_encode", st);
+    hipLaunchKernelGGL(k_encode, dim3(blocks), dim3(LZ_TPB), 0, st, raw, code, len, cls256_dev);
+    timer->end(st);
     LZ_HIP(hipGetLastError());
     return 0;
 }
@@ -659,20 +661,25 @@ void lz_phase_clocks_print()
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof(h)) != hipSuccess) return;
     fprintf(stderr, "[lzgpu phase clocks] probe_part:");
     for (int k = 0; k < 10; k++) fprintf(stderr, " %llu", h[k]);
-    fprintf(stderr, "\n[lzgpu phase clocks] settle (walker work, walker barrier wait, sorter work, sorter barrier wait; cycles summed over the 256 partitions):");
-    for (int k = 16; k < 20; k++) fprintf(stderr, " %llu", h[k]);
+    fprintf(stderr, "\n[lzgpu phase clocks] settle (walker work, walker barrier wait, sorter work, sorter barrier wait, extensions of wave 0: cycles, count; cycles summed over the 256 partitions):");
+    for (int k = 16; k < 22; k++) fprintf(stderr, " %llu", h[k]);
     fprintf(stderr, "\n");
 }
 // k_settle2: a walking wave's (slots 16, 17) and a sorting wave's (18, 19) cycles of work / of waiting at the tile barrier
 #define LZ_S2_CLK_BEGIN(who) unsigned long long _s2a = (who) ? __builtin_readcyclecounter() : 0ull, _s2b = 0ull
 #define LZ_S2_CLK_MID(who, slot) do { if (who) { _s2b = __builtin_readcyclecounter(); atomicAdd(&g_phase_clk[slot], _s2b - _s2a); } } while (0)
 #define LZ_S2_CLK_END(who, slot) do { if (who) atomicAdd(&g_phase_clk[slot], __builtin_readcyclecounter() - _s2b); } while (0)
+// ... of the walker's work: cycles in the wave-cooperative extensions of SLOW records (slot 20) and how many (21)
+#define LZ_S2_CLK_EXT_BEGIN(who, m) const unsigned long long _s2x = (who) ? __builtin_readcyclecounter() : 0ull; const unsigned _s2n = (unsigned)__popcll(m)
+#define LZ_S2_CLK_EXT_END(who) do { if (who) { atomicAdd(&g_phase_clk[20], __builtin_readcyclecounter() - _s2x); atomicAdd(&g_phase_clk[21], (unsigned long long)_s2n); } } while (0)
 #else
 #define LZ_CLK_DECL
 #define LZ_CLK(slot)
 #define LZ_S2_CLK_BEGIN(who)
 #define LZ_S2_CLK_MID(who, slot)
 #define LZ_S2_CLK_END(who, slot)
+#define LZ_S2_CLK_EXT_BEGIN(who, m)
+#define LZ_S2_CLK_EXT_END(who)
 void lz_phase_clocks_print() {}
 #endif
 #ifndef LZ_PP_TPB
@@ -789,17 +796,18 @@ __device__ __forceinline__ u32 lz_exscan256(u32 v, u32* wtot /*LDS, [4]*/)
 struct LzScanTask { u32 idx; s32 diag; LzLutScan L, R; };
 static_assert(sizeof(LzScanTask) == 64, "LzScanTask: one 64-byte line per task");
 #define LZ_SC_TPB 512                                // k_scan_hits<1/2>, k_scan_tasks regions; k_scan_hits<0> picks its own size (TPB template parameter)
-struct LzScanShared {
+template <int MODE> struct LzScanShared {
     union {
         LzLutEntry lut[LZ_LUT_TOTAL];                                   // MODE 0/1: the two look-up tables (64 KiB)
         struct { s32 tab[LZ_NCLASS * LZ_NCLASS]; s32 tab8[64]; } bc;    // MODE 2: the byte-code scans' tables
     };
+    s32 ctab[MODE == 1 ? LZ_NCLASS * LZ_NCLASS : 1];                    // MODE 1: the class table (a special base is scored from it)
 };
 
 // one round of k_scan_hits<0/1>: both scans' first windows of the hit `key`, whose windows (rawl, rawr) are loaded.
 // MODE 0 heads run without limit tests: a side with less than 60 bases of room is left to k_scan_tasks.
 template <bool SP>
-__device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzLutParams& Q, const LzLutEntry* lut, u64 key, bool valid,
+__device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzLutParams& Q, const LzLutEntry* lut, const s32* ctab, u64 key, bool valid,
                                               const LzLutRaw<SP>& rawl, const LzLutRaw<SP>& rawr, u32 idx, u32 lane,
                                               u32* __restrict__ summ, LzScanTask* __restrict__ my_tasks, u32& my_n, u32 region_cap)
 {
@@ -808,7 +816,7 @@ __device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzL
     lz_lut_init(key, P.tlen, P.qlen, diag, L, R);
     if (!valid) { L.alive = 0; R.alive = 0; }
     const bool ql = L.alive && !HLIM && L.room < (u32)LZ_LUT_WIN_B, qr = R.alive && !HLIM && R.room < (u32)LZ_LUT_WIN_B;
-    lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr);
+    lz_lut_window_pair<SP, HLIM>(Q, lut, diag, L, R, rawl, rawr, L.alive && !ql, R.alive && !qr, ctab);
     const bool more = valid && (L.alive == 1 || R.alive == 1);
     const u64 mm = __ballot(more);
     bool queued = false;
@@ -873,8 +881,9 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
             u32* __restrict__ summ, LzScanTask* __restrict__ tasks, u32* __restrict__ n_tasks, u32 region_cap)
 {
-    __shared__ LzScanShared sh;
+    __shared__ LzScanShared<MODE> sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    if (MODE == 1) { for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += TPB) sh.ctab[k] = score_tab_g[k]; }
     if (MODE < 2) { for (u32 k = tid; k < LZ_LUT_TOTAL; k += TPB) sh.lut[k] = lut_g[k]; }
     else {
         for (u32 k = tid; k < LZ_NCLASS * LZ_NCLASS; k += TPB) sh.bc.tab[k] = score_tab_g[k];
@@ -882,6 +891,7 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
     }
     __syncthreads();
     const LzLutEntry* lut = sh.lut;
+    const s32* const ctab = sh.ctab;
     constexpr bool SP = MODE == 1;
     constexpr u32 SPAN = 64u * LZ_SC_ROUNDS;
     static_assert(LZ_SC_ROUNDS == 4, "the round pipeline below is written out for four rounds per span");
@@ -923,14 +933,14 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
             const bool more_spans = span + wstride < nspans;
             u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             lz_scan_fetch<SP>(Q, k1, bl, br);
-            lz_scan_round<SP>(P, Q, lut, k0, lane < span_n, al, ar, ib, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k0, lane < span_n, al, ar, ib, lane, summ, my_tasks, my_n, region_cap);
             if (more_spans) load_keys(span + wstride, n0, n1, n2, n3);
             lz_scan_fetch<SP>(Q, k2, al, ar);
-            lz_scan_round<SP>(P, Q, lut, k1, lane + 64u < span_n, bl, br, ib + 64u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k1, lane + 64u < span_n, bl, br, ib + 64u, lane, summ, my_tasks, my_n, region_cap);
             lz_scan_fetch<SP>(Q, k3, bl, br);
-            lz_scan_round<SP>(P, Q, lut, k2, lane + 128u < span_n, al, ar, ib + 128u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k2, lane + 128u < span_n, al, ar, ib + 128u, lane, summ, my_tasks, my_n, region_cap);
             if (more_spans) lz_scan_fetch<SP>(Q, n0, al, ar);
-            lz_scan_round<SP>(P, Q, lut, k3, lane + 192u < span_n, bl, br, ib + 192u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k3, lane + 192u < span_n, bl, br, ib + 192u, lane, summ, my_tasks, my_n, region_cap);
             if (!more_spans) break;
             span += wstride; k0 = n0; k1 = n1; k2 = n2; k3 = n3;
         }
@@ -940,11 +950,13 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut_g, const LzScanTask* __restrict__ tasks,
+k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut_g, const s32* __restrict__ score_tab_g, const LzScanTask* __restrict__ tasks,
              const u32* __restrict__ n_tasks, u32 n_regions, u32 region_cap, u32* __restrict__ summ)
 {
     __shared__ LzLutEntry lut[LZ_LUT_TOTAL];
+    __shared__ s32 ctab[MODE == 1 ? LZ_NCLASS * LZ_NCLASS : 1];
     for (u32 k = threadIdx.x; k < LZ_LUT_TOTAL; k += 256) lut[k] = lut_g[k];
+    if (MODE == 1) for (u32 k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += 256) ctab[k] = score_tab_g[k];
     __syncthreads();
     constexpr bool SP = MODE == 1;
     for (u32 region = blockIdx.x; region < n_regions; region += gridDim.x) {
@@ -952,8 +964,8 @@ k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut
         for (u32 k = threadIdx.x; k < nt; k += 256u) {
             const LzScanTask t = tasks[(size_t)region * region_cap + k];
             LzLutScan L = t.L, R = t.R;
-            while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SP>(Q, lut, t.diag, L);
-            while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SP>(Q, lut, t.diag, R);
+            while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SP>(Q, lut, t.diag, L, ctab);
+            while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SP>(Q, lut, t.diag, R, ctab);
             summ[t.idx] = lz_lut_summary(L, R, P.min_score);
         }
     }
@@ -1061,7 +1073,10 @@ static void lz_scan_geometry(LzCtx& c, int mode, u64 n, u32& grid, u32& n_region
     const u64 nspans = (n + 64u * LZ_SC_ROUNDS - 1) / (64u * LZ_SC_ROUNDS), want = (nspans + wpg - 1) / wpg;
     grid = (u32)std::min<u64>(want ? want : 1, (u64)wgs * (u64)cus);
     n_regions = grid * wpg;
-    region_cap = (u32)std::min<u64>(n / 32 / n_regions + 64, 1u << 20);   // (64 B each; ~3 % of the hits become tasks: 1/32 of them fit, 2 GiB less to allocate than with 1/8)
+    // (64 B each; ~3 % of the hits become tasks on plain sequences: 1/32 of them fit, 2 GiB less to allocate than with 1/8.
+    // With special bytes that do not end a scan -- IUPAC codes -- every window that meets one goes on as a task as well:
+    // 1/12, or the overflow lands on phase B's slow path: 1 % of the hits there took k_settle2 from 20 to 84 ms.)
+    region_cap = (u32)std::min<u64>(n / (mode == 1 ? 12 : 32) / n_regions + 64, 1u << 20);
     static const char* force = getenv("LZGPU_TASK_REGION_CAP");  // test hook: tiny regions, so that hits find theirs full
     if (force && atoi(force) > 0) region_cap = (u32)atoi(force);
 }
@@ -1104,8 +1119,8 @@ int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const Lz
     LZ_HIP(hipGetLastError());
     if (mode < 2) {
         c.timer.begin("k_scan_tasks", st);
-        if (mode == 0) hipLaunchKernelGGL(k_scan_tasks<0>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, tasks, ntk, n_regions, task_cap, summ);
-        else           hipLaunchKernelGGL(k_scan_tasks<1>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, tasks, ntk, n_regions, task_cap, summ);
+        if (mode == 0) hipLaunchKernelGGL(k_scan_tasks<0>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
+        else           hipLaunchKernelGGL(k_scan_tasks<1>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
         c.timer.end(st);
         LZ_HIP(hipGetLastError());
     }
@@ -1230,6 +1245,9 @@ __device__ LzCoopSide lz_coop_extend_wave(const LzExtendParams& P, const s32* ta
 // running count.  (Round 2 took the rank from the return value of a same-address LDS atomic add and repaired
 // disorder after the fact, which leans on an order the ISA does not promise; here no order is assumed anywhere.)
 #define LZ_S2_TPB     1024
+#ifndef LZ_S2_WALK_PRIO
+#define LZ_S2_WALK_PRIO 0
+#endif
 #ifndef LZ_S2_WALKW
 #define LZ_S2_WALKW   4                                  // walking waves: 256 / LZ_S2_WALKW buckets each
 #endif
@@ -1344,6 +1362,9 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
     }
     __syncthreads();
     __syncthreads();
+#if LZ_S2_WALK_PRIO
+    __builtin_amdgcn_s_setprio(LZ_S2_WALK_PRIO);                // the walk is the critical path of a tile: its wave goes first on its SIMD
+#endif
     constexpr u32 BPW = LZ_NBIN / LZ_S2_WALKW;                   // buckets (= walking lanes) per walking wave
     const bool wl = lane < BPW;
     const u32 bucket = (w * BPW + lane) & (LZ_NBIN - 1);        // the lane's bucket
@@ -1388,6 +1409,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
                 }
                 u64 mask = __ballot(pending);
                 if (!mask) break;
+                LZ_S2_CLK_EXT_BEGIN(tid == 0, mask);
                 while (mask) {                                  // the wave extends the pending hits, one at a time
                     const int src = (int)__ffsll((long long)mask) - 1;
                     mask &= mask - 1;
@@ -1412,6 +1434,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
                         p++;
                     }
                 }
+                LZ_S2_CLK_EXT_END(tid == 0);
             }
             n_ext += ne; n_bp += nb;
         }
@@ -1430,7 +1453,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s)
 {
-    c.timer.begin("k_settle", s);
+    c.timer.begin("k_settle2", s);
     static bool attr_set = false;
     if (!attr_set) { LZ_HIP(hipFuncSetAttribute((const void*)k_settle2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzSettle2Shared))); attr_set = true; }
     hipLaunchKernelGGL(k_settle2, dim3(LZ_NBIN), dim3(LZ_S2_TPB), sizeof(LzSettle2Shared), s, P, recs, bin_base, diag_end, score_tab, out, out_count, out_cap, counters);

@@ -167,6 +167,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
     std::vector<LzLutEntry> lut(2 * LZ_LUT_ENTRIES);
     if (scan_mode < 2) lzh_lut_build(M4, a->xdrop, lut.data());
     LzLutParams Q; Q.t2 = t2.data(); Q.q2 = q2.data(); Q.tsp = tsp.data(); Q.qsp = qsp.data(); Q.xdrop = a->xdrop;
+    Q.t2x = nullptr; Q.tspx = nullptr; Q.tcode = tc; Q.qcode = qc;
     for (auto& ch : chunks) {
         std::vector<u64> keys(ch.nh);
         for (u32 i = ch.i0; i < ch.i1; i++)
@@ -180,7 +181,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
         for (size_t i = 0; i < keys.size(); i++) {
             u32 sm;
             if (scan_mode == 0)      sm = lz_lut_probe_hit<false>(Q, lut.data(), P.tlen, P.qlen, P.min_score, keys[i]);
-            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), P.tlen, P.qlen, P.min_score, keys[i]);
+            else if (scan_mode == 1) sm = lz_lut_probe_hit<true>(Q, lut.data(), P.tlen, P.qlen, P.min_score, keys[i], tab);
             else                     sm = lz_probe_hit(P, tab, tab8, P.cls8 != 0, keys[i]);
             rec[i] = lz_hit_record(keys[i], sm);
         }

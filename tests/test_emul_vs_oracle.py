@@ -131,9 +131,9 @@ def test_scan_modes_cover_lut_and_byte_code_paths(em, monkeypatch):
         assert _mode(em) == int(forced)
         _check(em, ta, qa, cap=5000)
     monkeypatch.delenv("EMUL_SCAN_MODE")
-    qr = q.copy(); qr[::997] = ord("R")                    # an IUPAC byte scores fillScore (-100): not a scan terminator
-    _check(em, t, qr, cap=50000)
-    assert _mode(em) == 2
+    qr = q.copy(); qr[::997] = ord("R")                    # an IUPAC byte scores fillScore (-100): not a scan terminator --
+    _check(em, t, qr, cap=50000)                           # consumed with its real score, the scan goes on behind it (round 4)
+    assert _mode(em) == 1
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -156,6 +156,31 @@ def test_lut_scans_with_dense_specials_and_short_sequences(em, seed):
     _check(em, t[:300], q[:200], pattern="11111111", wt=0, hsp_threshold=800)          # everything within reach of an end
     _check(em, t, q, xdrop=374, hsp_threshold=1500)         # three bases after a maximum set inside a group can lose 375 > xDrop: not eligible
     assert _mode(em) == 2
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_lut_scans_through_special_bytes_that_do_not_end_a_scan(em, seed):
+    """IUPAC bytes (fillScore -100 in lastz's matrices, partial credit in the many-class matrix) single, in pairs and in
+    runs, next to the seeds and at group / window boundaries: a scan consumes them with their real scores and goes on
+    behind them (a new window from the next base); lower case and N (-1000) still end it"""
+    rng = np.random.default_rng(seed)
+    t, q = seqio.synth_pair(40000, 30000, seed=200 + seed, block_min=300, block_max=3000)
+    t = t.copy(); q = q.copy()
+    iupac = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
+    for arr in (t, q):
+        n = len(arr)
+        idx = rng.integers(0, n, n // 25)
+        arr[idx] = iupac[rng.integers(0, len(iupac), len(idx))]          # scattered, every ~25 bases: several per window
+        for s in rng.integers(0, n - 20, 40):
+            k = int(rng.integers(2, 12))
+            arr[s:s + k] = iupac[rng.integers(0, len(iupac), k)]         # runs: one window per base
+        arr[rng.integers(0, n, n // 300)] |= 0x20                        # and a few bytes that do end a scan
+    _, masked = H.scoring()
+    _check(em, t, q, masked=masked, hsp_threshold=1800, cap=30000)
+    assert _mode(em) == 1
+    _check(em, t, q, masked=H.many_class_scoring(), hsp_threshold=1800, xdrop=600)
+    assert _mode(em) == 1
+    _check(em, t[:500], q[:400], pattern="11111111", wt=0, masked=masked, hsp_threshold=600)
 
 
 def test_host_finish_with_many_candidates(em):

@@ -124,3 +124,73 @@ def test_two_ranks_merge_line_oriented_formats(pair, fmt):
     assert len(drop(merged).splitlines()) > 20
     for r in (0, 1):
         assert "[lzgpu] gapped: done on the GPU" in errs[r]
+
+
+def _bench(args, nproc, port, env_extra=None, timeout=900):
+    import json, sys
+    env = dict(os.environ); env.update({"LZ_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1"}); env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(H.ROOT, "bench.py")] if nproc == 1 else \
+          [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(H.ROOT, "bench.py")]
+    p = subprocess.run(cmd + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=H.ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SHAPE = ["--steps", "1", "--warmup", "0", "--tlen-multi", "4000000", "--q-units", "3", "--q-unit-len", "1500000", "--no-cpu-baseline"]
+
+
+def test_bench_two_ranks_search_and_gapped_stage_equal_one_rank():
+    """bench.py's N > 1 code path: two ranks (gloo stands in for RCCL, which refuses two ranks on one
+    device), every unit searched AND gapped-extended, B3 of unit k beside B2 of unit k+1 on a second host thread and
+    stream -- the merged HSPs and alignments are those of one rank doing all units."""
+    two = _bench(["--gpus", "2"] + SHAPE, 2, 29541)
+    one = _bench(["--gpus", "1", "--force-multi"] + SHAPE, 1, 0)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["hsps_merged"] == one["hsps_merged"] > 1000
+    assert two["alignments"] == one["alignments"] > 20
+    assert two["alignments_sha"] == one["alignments_sha"]
+    assert two["units_per_rank"] == [3, 3] and not two["bucket_owners"]
+    kinds = {k for _, k, _, _ in two["timeline_rank0_last_step"]}
+    assert kinds == {"search", "gapped"}
+    for r in two["per_rank"]:
+        assert r["search_s"] > 0 and r["gapped_s"] > 0
+    assert 0 < two["table_build_and_broadcast_share_of_step"] < 1
+
+
+def test_bench_bucket_owners_inside_the_units():
+    """fewer units than ranks: B2 sharded inside every unit by hashed-diagonal ownership, the parts merged on the rank
+    that runs the unit's gapped stage -- same HSPs, same alignments as whole units on one rank"""
+    shape = ["--steps", "1", "--warmup", "0", "--tlen-multi", "4000000", "--q-units", "1", "--q-unit-len", "2000000", "--no-cpu-baseline"]
+    own = _bench(["--gpus", "2", "--bucket-owners", "always"] + shape, 2, 29543)
+    one = _bench(["--gpus", "1", "--force-multi"] + shape, 1, 0)
+    assert own["bucket_owners"] and not one["bucket_owners"]
+    assert own["hsps_merged"] == one["hsps_merged"] > 500
+    assert own["alignments_sha"] == one["alignments_sha"]
+
+
+def test_a_rank_on_the_second_device_binds_every_thread_to_it():
+    """HIP's current device is per host thread.  With LOCAL_RANK=1 every allocation and launch of the
+    library -- the caller's thread, lzgpu_init_async's, the gapped batch's workers -- must be on device 1."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    code = ("import numpy as np, torch\n"
+            "from lastz_amd import lzgpu, seqio\n"
+            "from oracle import lzo\n"
+            "lib = lzgpu.Lib(); lib.L.lzgpu_init_async(-1); lib.init(-1)\n"
+            "assert lib.L.lzgpu_device_index() == 1\n"
+            "t, q = seqio.synth_pair(400000, 400000, seed=5)\n"
+            "free0 = torch.cuda.mem_get_info(0)[0]\n"
+            "lib.table_prepare(t, lib.seed(), lzo.upper_nuc_to_bits())\n"
+            "_, masked = lzo.hoxd70_scoring()\n"
+            "hs = lib.seed_hit_search(masked, q=q)\n"
+            "assert len(hs) > 10\n"
+            "assert abs(torch.cuda.mem_get_info(0)[0] - free0) < (64 << 20), 'the library allocated on device 0'\n"
+            "print('ok')\n")
+    import sys
+    env = dict(os.environ); env["LOCAL_RANK"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=600)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]

@@ -189,12 +189,38 @@ def test_scan_modes_lut_and_byte_code(gpu):
                 assert gpu.last_scan_mode() == max(forced, 1)
             gpu.set_hit_capacity(1 << 28)
         gpu.set_scan_mode(0)
-        qr = q.copy(); qr[::997] = ord("R")                # fillScore (-100) does not end a scan: byte-code scans
-        tab = _prep(gpu, t)
+        qr = q.copy(); qr[::997] = ord("R")                # fillScore (-100) does not end a scan: consumed with its real score,
+        tab = _prep(gpu, t)                                # the scan goes on behind it (round 4; byte-code scans before)
         _same_hsps(gpu, tab, qr, masked)
-        assert gpu.last_scan_mode() == 2
+        assert gpu.last_scan_mode() == 1
     finally:
         gpu.set_scan_mode(0); gpu.set_hit_capacity(1 << 28)
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_lut_scans_through_special_bytes_that_do_not_end_a_scan(gpu, seed):
+    """IUPAC bytes single, in pairs and in runs (fillScore -100 in lastz's matrices, partial credit in the many-class
+    matrix): a scan consumes them with their real scores and goes on behind them; lower case still ends it"""
+    rng = np.random.default_rng(seed)
+    t, q = seqio.synth_pair(400000, 300000, seed=200 + seed, block_min=300, block_max=3000)
+    t = t.copy(); q = q.copy()
+    iupac = np.frombuffer(b"RYKMSWBDHV", dtype=np.uint8)
+    for arr in (t, q):
+        n = len(arr)
+        idx = rng.integers(0, n, n // 25)
+        arr[idx] = iupac[rng.integers(0, len(iupac), len(idx))]
+        for s in rng.integers(0, n - 20, 400):
+            k = int(rng.integers(2, 12))
+            arr[s:s + k] = iupac[rng.integers(0, len(iupac), k)]
+        arr[rng.integers(0, n, n // 300)] |= 0x20
+    _, masked = H.scoring()
+    tab = _prep(gpu, t)
+    for _, _, qq in H.strands(q):
+        _same_hsps(gpu, tab, qq, masked, hsp_threshold=1800)
+    assert gpu.last_scan_mode() == 1
+    for _, _, qq in H.strands(q):
+        _same_hsps(gpu, tab, qq, H.many_class_scoring(), hsp_threshold=1800, xdrop=600)
+    assert gpu.last_scan_mode() == 1
 
 
 @pytest.mark.parametrize("seed", [1, 2])
