@@ -315,7 +315,7 @@ int lzgpu_dp_longest(uint64_t out[4], int reset);
  * lists by them reproduces the single-process list exactly.  Counters: raw_hits / extensions / bp_extended /
  * hsps are partitioned, words is replicated.  Default (1, 0) = everything. */
 int lzgpu_set_bucket_owner(uint32_t n_owners, uint32_t owner);
-/* Which phase-A scanner the last lzgpu_seed_hit_search used: 0 / 1 = three bases per step through the look-up
+/* Which phase-A scanner the last lzgpu_seed_hit_search used: 0 / 1 = four bases per step through the look-up
  * table on 2-bit codes, without / with masks for bytes outside A,C,G,T; 2 = the byte-code scans (matrices or
  * xDrop values outside the table's preconditions, lastz_amd/csrc/lz_lut.hpp); -1 before the first search.
  * Results are identical in every mode; lzgpu_set_scan_mode(1|2) (or LZGPU_SCAN_MODE in the environment at

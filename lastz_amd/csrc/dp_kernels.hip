@@ -430,7 +430,9 @@ struct HipDpExec : LzDpExecutor {
             std::stable_sort(ids.begin(), ids.end(), [&](u32 a, u32 b) { return jobs[a].est_rows > jobs[b].est_rows; });
         static const bool uniform_slots = getenv("LZGPU_DP_UNIFORM_SLOTS") != nullptr;     // A/B aid: round 2's arena
         u32 slot = slot_tb;
-        bool first_try = !uniform_slots;
+        // (a launch of a few DPs -- the later rounds of a strand -- takes uniform slots at once: a DP that overflows its
+        // estimated slot costs a launch of its own, 2.8 ms for six DPs on the bench pair, and 256 uniform slots are 2 GiB)
+        bool first_try = !uniform_slots && jobs.size() > 256;
         while (!ids.empty() || !wide_ids.empty()) {
             // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch
             const u64 per = (u64)slot + (u64)(slot / 16 + 64) * 4 + (u64)(slot / 32 + 64) * 4;
@@ -441,8 +443,22 @@ struct HipDpExec : LzDpExecutor {
                 const bool wide = pass == 1;
                 const std::vector<u32>& todo = wide ? wide_ids : ids;
                 const u64 cap = wide ? std::min<u64>(max_jobs, 2048) : max_jobs;      // (2048 rings = 1.8 GiB)
-                for (size_t base = 0; base < todo.size(); base += cap) {
-                    std::vector<u32> part(todo.begin() + base, todo.begin() + std::min<size_t>(todo.size(), base + cap));
+                for (size_t base = 0, stop = 0; base < todo.size(); base = stop) {
+                    // a launch's share of the jobs: `cap` of them at uniform slots; on the first try -- slots sized from the row
+                    // estimates, a third of that -- as many as keep the arenas within the same 48 GiB (the uniform count cut
+                    // the bench pair's 4596 DPs into launches of 4468 and 128: 4.7 ms for the second)
+                    if (!first_try || wide) stop = std::min<size_t>(todo.size(), base + cap);
+                    else {
+                        u64 bytes = 0;
+                        for (stop = base; stop < todo.size(); stop++) {
+                            u64 sl = std::max<u64>((u64)jobs[todo[stop]].est_rows * 1000u, 2u << 20);
+                            sl = std::min<u64>((sl + 65535u) & ~65535ull, slot);
+                            const u64 need = sl + (sl / 16 + 64) * 4 + (sl / 32 + 64) * 4;
+                            if (stop > base && bytes + need > (48ull << 30)) break;
+                            bytes += need;
+                        }
+                    }
+                    std::vector<u32> part(todo.begin() + base, todo.begin() + stop);
                     if ((rc = launch(jobs, part, slot, res, wide, first_try))) return rc;
                     std::vector<u32> good;
                     for (u32 id : part) {

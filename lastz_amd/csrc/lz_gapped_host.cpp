@@ -11,7 +11,58 @@
 #include "lz_gapped_host.hpp"
 #include "lz_host.hpp"
 
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
+
 #define SUBM(m, r, c) ((m)[((size_t)(r) << 8) | (size_t)(c)])
+
+// A few helper threads for the host loops of one big problem (a 50 Mbp strand: 79 k anchors, 1150 alignments built per
+// round).  They sleep on a condition variable between the rounds and spin during a commit pass (begin_burst /
+// end_burst): a fork-join then costs a few microseconds, so that loops of a few hundred items are worth handing out
+// (starting a std::thread per loop cost 30-50 us each: round 3's attempts at this lost what they won).
+namespace {
+class ForkJoin {
+    std::vector<std::thread> th;
+    std::mutex m; std::condition_variable cv;
+    std::atomic<bool> burst{false}, quit{false};
+    std::atomic<unsigned long long> gen{0};
+    std::atomic<size_t> next{0}; std::atomic<int> busy{0};
+    size_t n = 0, chunk = 1; const std::function<void(size_t, size_t)>* fn = nullptr;
+    void drain() { for (;;) { const size_t a = next.fetch_add(chunk); if (a >= n) break; (*fn)(a, a + chunk < n ? a + chunk : n); } }
+    void worker()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            if (!burst.load(std::memory_order_acquire)) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return burst.load() || quit.load(); });
+            }
+            if (quit.load()) return;
+            const unsigned long long g = gen.load(std::memory_order_acquire);
+            if (g == seen) { std::this_thread::yield(); continue; }
+            seen = g;
+            drain();
+            busy.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+public:
+    explicit ForkJoin(unsigned workers) { try { for (unsigned k = 0; k < workers; k++) th.emplace_back([this] { worker(); }); } catch (const std::system_error&) {} }
+    ~ForkJoin() { { std::lock_guard<std::mutex> lk(m); quit.store(true); } cv.notify_all(); for (auto& t : th) t.join(); }
+    void begin_burst() { if (th.empty()) return; { std::lock_guard<std::mutex> lk(m); burst.store(true, std::memory_order_release); } cv.notify_all(); }
+    void end_burst() { burst.store(false, std::memory_order_release); }
+    // f(lo, hi) over [0, count) in chunks, on the helpers and the caller; returns when every chunk is done
+    void run(size_t count, size_t chunk_, const std::function<void(size_t, size_t)>& f)
+    {
+        if (th.empty() || !burst.load() || count <= chunk_) { f(0, count); return; }
+        n = count; chunk = chunk_; fn = &f; next.store(0);
+        busy.store((int)th.size());
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        drain();
+        while (busy.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+};
+}
 enum { OP_INS = 1, OP_DEL = 2, OP_SUB = 3 };
 #define WORST_SCORE (-0x7FFFFFFF - 1)
 
@@ -134,11 +185,41 @@ static int msp_left_right_plain(const LzHostSnapshot& S, u32 pos1, u32 pos2, Nei
 }
 
 // align_left_right, src/gapped_extend.c:4078-4180
+struct LrAcc {
+    u32 rob = 0xFFFFFFFFu, rot = 0xFFFFFFFFu, lob = 0xFFFFFFFFu, lot = 0xFFFFFFFFu;
+    s32 m_rob = -1, m_rot = -1, m_lob = -1, m_lot = -1, b_rob = -1, b_rot = -1, b_lob = -1, b_lot = -1;
+};
+static void lr_visit(const LzHostSnapshot& S, s32 ai, u32 pos1, u32 pos2, u32 end1, u32 end2, LrAcc& A)
+{
+    const LzDpAlign& al = S.aligns[ai];
+    s32 bp = -1, k; s32 x;
+    for (k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= pos1) { bp = k; break; }
+    if (bp >= 0 && S.segs[bp].b1 <= pos1) {
+        const LzDpSeg& g = S.segs[bp];
+        x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+        if (x > 0 && (u32)x < A.rob) { A.rob = (u32)x; A.m_rob = ai; A.b_rob = bp; }
+        else if (x < 0 && (u32)(-x) < A.lob) { A.lob = (u32)(-x); A.m_lob = ai; A.b_lob = bp; }
+    }
+    if (bp >= 0) {
+        s32 bq = -1;
+        for (k = bp; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= end1) { bq = k; break; }
+        if (bq >= 0) {
+            const LzDpSeg& g = S.segs[bq];
+            x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, end2) + LZ_SDIFF(end1, g.b1) : LZ_SDIFF(g.b2, end2);
+            if (x > 0 && (u32)x < A.rot) { A.rot = (u32)x; A.m_rot = ai; A.b_rot = bq; }
+            else if (x < 0 && (u32)(-x) < A.lot) { A.lot = (u32)(-x); A.m_lot = ai; A.b_lot = bq; }
+        }
+    }
+}
+static void lr_store(LzDpAlign& m, const LrAcc& A)
+{
+    m.right_align1 = A.m_rob; m.right_seg1 = A.b_rob; m.right_align2 = A.m_rot; m.right_seg2 = A.b_rot;
+    m.left_align1 = A.m_lob;  m.left_seg1 = A.b_lob;  m.left_align2 = A.m_lot;  m.left_seg2 = A.b_lot;
+}
 static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
 {
     const u32 pos1 = m.pos1, pos2 = m.pos2, end1 = m.end1, end2 = m.end2;
-    u32 rob = 0xFFFFFFFFu, rot = 0xFFFFFFFFu, lob = 0xFFFFFFFFu, lot = 0xFFFFFFFFu;
-    s32 m_rob = -1, m_rot = -1, m_lob = -1, m_lot = -1, b_rob = -1, b_rot = -1, b_lob = -1, b_lot = -1;
+    LrAcc A;
     // The reference walks every alignment and skips those that do not overlap [pos1, end1] in the target.  obi is ordered by
     // pos1 and obi_maxend[o] is the largest end1 of obi[0..o]: everything before the first o whose running maximum
     // reaches pos1 ends before pos1, everything from the first alignment that starts after end1 on starts after it --
@@ -146,31 +227,38 @@ static void align_left_right(const LzHostSnapshot& S, LzDpAlign& m)
     size_t o_lo = 0;
     { size_t lo = 0, hi = S.obi_maxend.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.obi_maxend[mid] >= pos1) hi = mid; else lo = mid + 1; } o_lo = lo; }
     for (size_t o = o_lo; o < S.obi.size(); o++) {
-        const s32 ai = S.obi[o];
-        const LzDpAlign& al = S.aligns[ai];
+        const LzDpAlign& al = S.aligns[S.obi[o]];
         if (al.pos1 > end1) break;
         if (al.end1 < pos1) continue;
-        s32 bp = -1, k; s32 x;
-        for (k = al.first_seg; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= pos1) { bp = k; break; }
-        if (bp >= 0 && S.segs[bp].b1 <= pos1) {
-            const LzDpSeg& g = S.segs[bp];
-            x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
-            if (x > 0 && (u32)x < rob) { rob = (u32)x; m_rob = ai; b_rob = bp; }
-            else if (x < 0 && (u32)(-x) < lob) { lob = (u32)(-x); m_lob = ai; b_lob = bp; }
-        }
-        if (bp >= 0) {
-            s32 bq = -1;
-            for (k = bp; k <= al.last_seg; k++) if (S.segs[k].type != LZ_HORZ_SEG && S.segs[k].e1 >= end1) { bq = k; break; }
-            if (bq >= 0) {
-                const LzDpSeg& g = S.segs[bq];
-                x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, end2) + LZ_SDIFF(end1, g.b1) : LZ_SDIFF(g.b2, end2);
-                if (x > 0 && (u32)x < rot) { rot = (u32)x; m_rot = ai; b_rot = bq; }
-                else if (x < 0 && (u32)(-x) < lot) { lot = (u32)(-x); m_lot = ai; b_lot = bq; }
-            }
-        }
+        lr_visit(S, S.obi[o], pos1, pos2, end1, end2, A);
     }
-    m.right_align1 = m_rob; m.right_seg1 = b_rob; m.right_align2 = m_rot; m.right_seg2 = b_rot;
-    m.left_align1 = m_lob;  m.left_seg1 = b_lob;  m.left_align2 = m_lot;  m.left_seg2 = b_lot;
+    lr_store(m, A);
+}
+// the reference's walk over every alignment, the yardstick of lzh_selftest_neighbours
+static void align_left_right_plain(const LzHostSnapshot& S, LzDpAlign& m)
+{
+    LrAcc A;
+    for (size_t o = 0; o < S.obi.size(); o++) {
+        const LzDpAlign& al = S.aligns[S.obi[o]];
+        if (al.pos1 > m.end1 || al.end1 < m.pos1) continue;
+        lr_visit(S, S.obi[o], m.pos1, m.pos2, m.end1, m.end2, A);
+    }
+    lr_store(m, A);
+}
+
+// get_above_below, src/gapped_extend.c:4043-4059: the first entry of oed that ends before a1 / of obi that starts after it
+// (the reference's linear walks as bisections: oed is ordered by decreasing end, obi by increasing start)
+static void above_below(const LzHostSnapshot& S, u32 a1, s32& below, s32& above)
+{
+    below = -1; above = -1;
+    { size_t lo = 0, hi = S.oed.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.oed[mid]].end1 >= a1) lo = mid + 1; else hi = mid; } if (lo < S.oed.size()) below = (s32)lo; }
+    { size_t lo = 0, hi = S.obi.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.obi[mid]].pos1 <= a1) lo = mid + 1; else hi = mid; } if (lo < S.obi.size()) above = (s32)lo; }
+}
+static void above_below_plain(const LzHostSnapshot& S, u32 a1, s32& below, s32& above)
+{
+    below = -1; above = -1;
+    for (size_t o = 0; o < S.oed.size(); o++) if (S.aligns[S.oed[o]].end1 < a1) { below = (s32)o; break; }
+    for (size_t o = 0; o < S.obi.size(); o++) if (S.aligns[S.obi[o]].pos1 > a1) { above = (s32)o; break; }
 }
 
 // insert_align, src/gapped_extend.c:4210-4245
@@ -184,9 +272,12 @@ static void insert_align(LzHostSnapshot& S, s32 ai)
     const size_t p_obi = p;
     { size_t lo = 0, hi = S.oed.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.oed[mid]].end1 > m.end1) lo = mid + 1; else hi = mid; } p = lo; }
     S.oed.insert(S.oed.begin() + p, ai);
-    S.obi_maxend.resize(S.obi.size());
-    u32 mx = p_obi ? S.obi_maxend[p_obi - 1] : 0u;               // the running maximum is unchanged in front of the new entry
-    for (size_t o = p_obi; o < S.obi.size(); o++) { const u32 e = S.aligns[S.obi[o]].end1; if (e > mx) mx = e; S.obi_maxend[o] = mx; }
+    // the running maximum of end1 along obi: unchanged in front of the new entry; behind it every value is the old one or
+    // the new alignment's end, whichever is larger -- and the old values only grow, so the walk stops at the first that
+    // is large enough (it used to recompute the whole tail: quadratic in the alignments)
+    const u32 before = p_obi ? S.obi_maxend[p_obi - 1] : 0u;
+    S.obi_maxend.insert(S.obi_maxend.begin() + p_obi, before > m.end1 ? before : m.end1);
+    for (size_t o = p_obi + 1; o < S.obi_maxend.size() && S.obi_maxend[o] < m.end1; o++) S.obi_maxend[o] = m.end1;
 }
 
 // score_alignment, src/gapped_extend.c:5631-5675
@@ -302,6 +393,29 @@ static bool align_touches(const LzHostSnapshot& S, const LzDpAlign& al, s64 r0, 
     return false;
 }
 
+// does an alignment committed since the snapshot (index >= k0) touch one of the two rectangles a cached DP pair explored?
+struct Rect2 { s64 lr0, lr1, lc0, lc1, rr0, rr1, rc0, rc1; };
+static bool touched_since(const LzHostSnapshot& S, size_t k0, const Rect2& q)
+{
+    const s64 row_lo = q.lr0 < q.rr0 ? q.lr0 : q.rr0, row_hi = q.lr1 > q.rr1 ? q.lr1 : q.rr1;
+    size_t lo = 0, hi = S.obi_maxend.size();
+    while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if ((s64)S.obi_maxend[mid] >= row_lo) hi = mid; else lo = mid + 1; }
+    for (size_t o = lo; o < S.obi.size(); o++) {
+        const s32 ai = S.obi[o];
+        const LzDpAlign& al = S.aligns[ai];
+        if ((s64)al.pos1 > row_hi) break;
+        if ((size_t)ai < k0) continue;
+        if (align_touches(S, al, q.lr0, q.lr1, q.lc0, q.lc1) || align_touches(S, al, q.rr0, q.rr1, q.rc0, q.rc1)) return true;
+    }
+    return false;
+}
+static bool touched_since_plain(const LzHostSnapshot& S, size_t k0, const Rect2& q)       // (every alignment: the yardstick)
+{
+    for (size_t ai = k0; ai < S.aligns.size(); ai++)
+        if (align_touches(S, S.aligns[ai], q.lr0, q.lr1, q.lc0, q.lc1) || align_touches(S, S.aligns[ai], q.rr0, q.rr1, q.rc0, q.rc1)) return true;
+    return false;
+}
+
 // lookup_partition (src/sequences.c:6536-...): the limits [low, high) of the partition holding pos
 static bool partition_limits(const u32* sep, u32 n_sep, u32 pos, u32 len, u32& low, u32& high)
 {
@@ -375,7 +489,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 
     // LZGPU_HOSTPROF=1: where the host time of the stage goes
     static const bool prof = getenv("LZGPU_HOSTPROF") != nullptr;
-    double t_sort = 0, t_window = 0, t_exec = 0, t_commit = 0, t_c_lr = 0, t_c_chk = 0, t_c_build = 0;
+    double t_sort = 0, t_window = 0, t_exec = 0, t_prebuild = 0, t_commit = 0, t_c_lr = 0, t_c_chk = 0, t_c_build = 0, t_c_alr = 0, t_c_ins = 0, t_c_cov = 0;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now();
     auto lap = [&](double& acc) { const double t = now(); acc += t - t_mark; t_mark = t; };
@@ -414,6 +528,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
 
     const u32 W = G.window ? G.window : 1024;
     u64 paired_bases = 0;
+    static const u32 helper_min = []() { const char* e = getenv("LZGPU_HELPER_MIN_ANCHORS"); return (u32)(e ? atoi(e) : 20000); }();   // (tests: 0)
+    ForkJoin helpers(n_anchors >= helper_min ? 3u : 0u);       // (small problems -- tweener windows -- stay on their own thread)
     // Which anchors of a window are worth a speculative DP.  Most anchors lie on the alignment an
     // earlier (better) anchor is about to produce -- the reference drops them in msp_left_right
     // without running a DP (98.5 % on the 10 Mbp pair).  An anchor within
@@ -430,6 +546,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // conditions hold against the alignments committed after the snapshot it ran against.
     struct Cached { u32 a1, a2; Neighbours nb; size_t n_snap; LzDpResult rl, rr; std::vector<u32> ol, orr; };
     std::unordered_map<u32, Cached> cache;
+    struct Prebuilt { Built b; std::vector<LzDpSeg> segs; bool have = false; };
+    std::vector<Prebuilt> prebuilt;                            // per SPECULATED entry of the window: what its commit would build
+    std::vector<u32> spec_of, spec_list;                       // entry -> its place in prebuilt / the speculated entries
     std::vector<Entry> entries;
     std::vector<u32> fresh;                                    // anchors launched in this round
     // the alignment committed for the selected anchor a deferred anchor was found near, remembered across windows:
@@ -500,9 +619,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
             if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
-            s32 below = -1, above = -1;                         // (first entry of oed that ends before a1 / of obi that starts after it)
-            { size_t lo = 0, hi = S.oed.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.oed[mid]].end1 >= a1) lo = mid + 1; else hi = mid; } if (lo < S.oed.size()) below = (s32)lo; }
-            { size_t lo = 0, hi = S.obi.size(); while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (S.aligns[S.obi[mid]].pos1 <= a1) lo = mid + 1; else hi = mid; } if (lo < S.obi.size()) above = (s32)lo; }
+            s32 below, above;
+            above_below(S, a1, below, above);
             // the partition holding the anchor bounds its extension, :1356-1372 / ydrop_align :2515-2531
             u32 low1, high1, low2, high2;
             if (!partition_limits(G.sep1, G.n_sep1, a1, G.tlen, low1, high1) || !partition_limits(G.sep2, G.n_sep2, a2, G.qlen, low2, high2)
@@ -538,6 +656,30 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         }
         st.rounds++; st.dp_runs += jobs.size();
         lap(t_exec);
+        // ---- what a commit builds from a DP pair -- the spliced script, its end trimming and rescoring, the pieces -- depends on
+        // the pair alone: done for every speculated entry of the window up front, on the helpers (splice_and_trim walks both
+        // sequences along the whole alignment: 2/3 of the serial pass it is taken out of)
+        spec_of.assign(entries.size(), 0xFFFFFFFFu);
+        spec_list.clear();
+        for (size_t e = 0; e < entries.size(); e++) if (entries[e].speculated) { spec_of[e] = (u32)spec_list.size(); spec_list.push_back((u32)e); }
+        prebuilt.clear(); prebuilt.resize(spec_list.size());
+        {
+            const std::function<void(size_t, size_t)> build = [&](size_t lo, size_t hi) {
+                for (size_t k = lo; k < hi; k++) {
+                    auto it = cache.find(entries[spec_list[k]].anchor_ix);   // (concurrent look-ups only: nothing is inserted or erased here)
+                    if (it == cache.end()) continue;
+                    const Cached& sp = it->second;
+                    Prebuilt& pb = prebuilt[k];
+                    splice_and_trim(G, sp.a1, sp.a2, sp.rl, sp.ol, sp.rr, sp.orr, pb.b);
+                    format_segments(pb.b, pb.segs);
+                    pb.have = true;
+                }
+            };
+            helpers.begin_burst();
+            helpers.run(spec_list.size(), helper_min ? 16 : 1, build);
+            helpers.end_burst();
+        }
+        lap(t_prebuild);
 
         // ---- commit in the reference's order
         bool cut = false;
@@ -580,19 +722,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             // (only alignments that overlap the two rectangles' rows can touch them: obi is ordered by pos1 and obi_maxend is
             // the running maximum of end1, so they are a stretch of obi found by bisection -- walking every alignment
             // committed since the snapshot was quadratic, 10 ms per strand at the north star's size)
-            auto touched_from = [&](size_t k0) {
-                const s64 row_lo = lr0 < rr0 ? lr0 : rr0, row_hi = lr1 > rr1 ? lr1 : rr1;
-                size_t lo = 0, hi = S.obi_maxend.size();
-                while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if ((s64)S.obi_maxend[mid] >= row_lo) hi = mid; else lo = mid + 1; }
-                for (size_t o = lo; o < S.obi.size(); o++) {
-                    const s32 ai = S.obi[o];
-                    const LzDpAlign& al = S.aligns[ai];
-                    if ((s64)al.pos1 > row_hi) break;
-                    if ((size_t)ai < k0) continue;
-                    if (align_touches(S, al, lr0, lr1, lc0, lc1) || align_touches(S, al, rr0, rr1, rc0, rc1)) return true;
-                }
-                return false;
-            };
+            const Rect2 rects = { lr0, lr1, lc0, lc1, rr0, rr1, rc0, rc1 };
+            auto touched_from = [&](size_t k0) { return touched_since(S, k0, rects); };
             // (a) same neighbour segments at the anchor as when it ran and nothing committed since
             //     touches what it explored: identical inputs wherever the DP looked;
             // (b) or no alignment at all touches what it explored: every bound (L, R, masks) the
@@ -609,23 +740,28 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
             st.truncated += (rl.truncated ? 1 : 0) + (rr.truncated ? 1 : 0);     // :3640-3661: the reference warns on stderr
-            Built b;
-            splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, b);
+            Prebuilt& pb = prebuilt[spec_of[e]];
+            if (!pb.have) { splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, pb.b); format_segments(pb.b, pb.segs); }
+            Built& b = pb.b;
+            std::vector<LzDpSeg>& segs = pb.segs;
             cache.erase(it);
-            std::vector<LzDpSeg> segs;
-            format_segments(b, segs);
             if (segs.empty()) continue;                        // empty alignment, :1401-1405
             if (!G.all_bounds && b.s < G.score_thresh) continue;     // :1419-1429
             LzDpAlign m; memset(&m, 0, sizeof(m));
             m.pos1 = b.start1; m.pos2 = b.start2; m.end1 = b.stop1; m.end2 = b.stop2;
             m.first_seg = (s32)S.segs.size(); m.last_seg = m.first_seg + (s32)segs.size() - 1;
+            const double tq3 = prof ? now() : 0;
             align_left_right(S, m);
+            if (prof) t_c_alr += now() - tq3;
             S.segs.insert(S.segs.end(), segs.begin(), segs.end());
             S.aligns.push_back(m);
             Info in; in.s = b.s; in.beg1 = b.start1 + 1; in.beg2 = b.start2 + 1; in.end1 = b.stop1 + 1; in.end2 = b.stop2 + 1;
             in.script.swap(b.script);
             info.push_back(std::move(in));
             insert_align(S, (s32)S.aligns.size() - 1);
+            const double tq4 = prof ? now() : 0;
+            if (prof) t_c_ins += tq4 - tq3;
+            struct LapC { double& acc; double t0; bool on; std::function<double()> clk; ~LapC() { if (on) acc += clk() - t0; } } lap_cov{ t_c_cov, tq4, prof, now };
             if (entries[e].near_slot < slot_align.size()) {
                 const u32 slot = entries[e].near_slot;
                 slot_align[slot] = (s32)S.aligns.size() - 1;
@@ -638,13 +774,12 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                         if (mem[k].e > e && on_alignment(S, al, mem[k].pos1, mem[k].pos2)) covered[mem[k].e] = 1;
                     }
                 };
-                if (mem.size() < 4096) check(0, mem.size());
-                else {
-                    const size_t nt = std::min<size_t>(8, mem.size() / 2048);
-                    std::vector<std::thread> th;
-                    for (size_t t = 1; t < nt; t++) th.emplace_back(check, mem.size() * t / nt, mem.size() * (t + 1) / nt);
-                    check(0, mem.size() / nt);
-                    for (auto& x : th) x.join();
+                if (mem.size() < (helper_min ? 8192u : 8u)) check(0, mem.size());
+                else {                                          // (an alignment that swallows thousands of anchors: worth waking the helpers)
+                    const std::function<void(size_t, size_t)> chk = check;
+                    helpers.begin_burst();
+                    helpers.run(mem.size(), helper_min ? 1024 : 1, chk);
+                    helpers.end_burst();
                 }
             }
             if (G.max_paired_bases) {                          // count_paired_bases, :5695-5706; the limit test of :1441-1459
@@ -657,8 +792,8 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         if (!cut) next = j;
         lap(t_commit);
     }
-    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, commit %.2f ms (neighbours %.2f, validity %.2f, build %.2f) (%u rounds)\n",
-                      t_sort, t_window, t_exec, t_commit, t_c_lr, t_c_chk, t_c_build, (unsigned)st.rounds);
+    if (prof) fprintf(stderr, "[lzgpu hostprof] gapped: sort %.2f ms, windows %.2f ms, DP launches %.2f ms, pre-build %.2f ms, commit %.2f ms (neighbours %.2f, validity %.2f, build %.2f: of which neighbours of the new alignment + lists %.2f [align_left_right %.2f], coverage of deferred anchors %.2f) (%u rounds)\n",
+                      t_sort, t_window, t_exec, t_prebuild, t_commit, t_c_lr, t_c_chk, t_c_build, t_c_ins, t_c_alr, t_c_cov, (unsigned)st.rounds);
 
     // ---- inhibitTrivial's test by sequence name (:1485-1545) cannot be made here: a result that holds a candidate for it
     // (one diagonal piece covering a whole partition pair of equal length, base for base the same) goes back undone
@@ -713,6 +848,19 @@ int lzh_selftest_neighbours(u32 seed, u32 n_aligns, u32 n_queries)
         Neighbours a, b;
         const int ra = msp_left_right(S, p1, p2, a), rb = msp_left_right_plain(S, p1, p2, b);
         if (ra != rb || (ra == 1 && (a.la != b.la || a.ls != b.ls || a.ra != b.ra || a.rs != b.rs))) bad++;
+        // the other bisected searches of the commit pass against the reference's linear walks
+        s32 b1, a1, b2, a2;
+        above_below(S, p1, b1, a1); above_below_plain(S, p1, b2, a2);
+        if (b1 != b2 || a1 != a2) bad++;
+        LzDpAlign m1; memset(&m1, 0, sizeof(m1));
+        m1.pos1 = p1; m1.pos2 = p2; m1.end1 = p1 + rnd() % 4000; m1.end2 = p2 + rnd() % 4000;
+        LzDpAlign m2 = m1;
+        align_left_right(S, m1); align_left_right_plain(S, m2);
+        if (memcmp(&m1, &m2, sizeof(m1)) != 0) bad++;
+        const s64 r0 = (s64)p1 - (s64)(rnd() % 3000), r1 = (s64)p1 + 2, c0 = (s64)p2 - (s64)(rnd() % 3000), c1 = (s64)p2 + 2;
+        const Rect2 q = { r0, r1, c0, c1, (s64)p1 - 2, (s64)p1 + (s64)(rnd() % 3000), (s64)p2 - 2, (s64)p2 + (s64)(rnd() % 3000) };
+        const size_t k0 = S.aligns.empty() ? 0 : rnd() % S.aligns.size();
+        if (touched_since(S, k0, q) != touched_since_plain(S, k0, q)) bad++;
     }
     return bad;
 }

@@ -13,7 +13,7 @@ u32  lzh_small_classes(const u8 rowc[256], const u8 colc[256]);    // 1 when eve
 double lzh_hsp_entropy(const u8* s, const u8* t, int len);
 
 // ---- phase-A look-up tables (lz_lut.hpp).  tocc / qocc say which byte values occur in the target / query.
-// lzh_lut_eligible: 1 when the scans of this (matrix, xDrop, sequences) can run three bases per step on 2-bit
+// lzh_lut_eligible: 1 when the scans of this (matrix, xDrop, sequences) can run four bases per step on 2-bit
 // codes -- M4 receives the 4 x 4 matrix over charToBits codes -- else 0 (the byte-code scans run instead).
 struct LzLutEntry;
 int  lzh_lut_eligible(const s32* sub, const int8_t ctb[256], const u8 tocc[256], const u8 qocc[256], s32 xdrop, s32 M4[16]);

@@ -264,7 +264,7 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
 }
 // the first windows of both scans of a hit (do_l / do_r: which of them this lane runs).  (Stepping the two windows
 // side by side in one instruction stream -- two dependent chains per lane -- was measured and lost: 138 VGPRs,
-// three waves per SIMD instead of four, k_probe_part 120 -> 167 ms per step.)
+// three waves per SIMD instead of four, the fused scan + partition kernel of round 2 120 -> 167 ms per step.)
 template <bool SPECIAL, bool LIMCHK>
 LZ_HD void lz_lut_window_pair(const LzLutParams& P, const LzLutEntry* lut, s32 diag, LzLutScan& L, LzLutScan& R,
                               const LzLutRaw<SPECIAL>& rawl, const LzLutRaw<SPECIAL>& rawr, bool do_l, bool do_r, const s32* ctab = nullptr)

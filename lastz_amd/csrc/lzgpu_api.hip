@@ -620,7 +620,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     const bool nibs = P.cls8 && c.target.have_nib && qs->have_nib;
     P.tnib = nibs ? c.target.nib.as<u8>() : nullptr; P.qnib = nibs ? qs->nib.as<u8>() : nullptr;
 
-    // phase A: three bases per step on 2-bit codes when the matrix, xDrop and the bytes that occur allow it
+    // phase A: four bases per step on 2-bit codes when the matrix, xDrop and the bytes that occur allow it
     // (mode 0 / 1 = without / with special-byte masks), else the byte-code scans (mode 2)
     LzLutParams Q;
     Q.t2 = c.target.two.as<u8>(); Q.q2 = qs->two.as<u8>(); Q.tsp = c.target.spc.as<u8>(); Q.qsp = qs->spc.as<u8>(); Q.xdrop = a->xdrop;

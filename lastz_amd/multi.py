@@ -186,10 +186,11 @@ def output_format(args):
 
 def line_oriented(fmt):
     """formats whose output is a header followed by self-contained records, nothing at the end and no state carried from
-    one unit to the next beyond AXT's running number (src/maf.c, src/axt.c, src/genpaf.c, src/cigar.c).  SAM is not
-    one of them: the reference prints an @SQ line whenever a query is loaded, before the unit's marker."""
+    one unit to the next beyond AXT's running number (src/maf.c, src/axt.c, src/genpaf.c, src/cigar.c).  SAM is one of
+    them as well: its @HD line opens the job and the @SQ lines of the target are printed once, when the first strand
+    starts (src/sam.c:195-250, `headerPrinted`) -- ahead of a rank's first unit marker, i.e. in its header."""
     base = re.split(r"[:+-]", fmt.lstrip("~"), 1)[0]
-    return base in ("maf", "axt", "waxt", "general", "mapping", "cigar", "differences")
+    return base in ("maf", "axt", "waxt", "general", "mapping", "cigar", "differences", "sam", "softsam")
 
 
 def split_marked(text):
@@ -237,7 +238,7 @@ def check_supported(target, args):
     """what the merger cannot put back together is refused before any rank starts"""
     fmt = output_format(args)
     if fmt != "lav" and not line_oriented(fmt):
-        raise ValueError("lastz_amd.multi merges LAV, MAF, AXT, general, cigar and differences output (got %s); run "
+        raise ValueError("lastz_amd.multi merges LAV, MAF, AXT, SAM, general, cigar and differences output (got %s); run "
                          "the formats the launcher does not know through a single lastz_gpu process" % fmt)
     for a in args:
         if a.startswith("--output=") or a == "--markend":

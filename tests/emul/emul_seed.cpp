@@ -174,7 +174,7 @@ extern "C" int emul_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint6
             if (cnt[i]) lz_fill_hits_at(qc, lo + i + 1, E.sd, E.wstart.data(), E.wpos.data(), keys.data() + (off[i] - ch.base));
         if (!a->extend) { for (u64 k : keys) { u32 p2 = (u32)k; plain.push_back({ p2 + (u32)(k >> 32), p2, L, 0 }); } continue; }
         // phase A on the hits in discovery order (look-up-table scans on 2-bit codes when the matrix allows it,
-        // k_probe_part<0/1>, else the byte-code scans, <2>), 8-byte records, stable partition by the high 8 hash
+        // k_scan_hits<0/1>, else the byte-code scans, <2>), 8-byte records, stable partition by the high 8 hash
         // bits; phase B (k_settle): per partition, tiles of LZ_ST_TILE records are dealt out to the 256 buckets
         // and every bucket walks its list in tile order
         std::vector<u64> rec(keys.size());

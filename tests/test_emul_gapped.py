@@ -89,6 +89,16 @@ def test_obstacle_course(L):
     assert st["rounds"] > 3
 
 
+def test_helper_threads_of_the_commit_pass():
+    """the fork-join helpers (alignments pre-built, deferred anchors checked against their slot's alignment on several
+    threads) only start for problems of >= 20 k anchors: here forced on, with chunks of one item, in a process of its own"""
+    import subprocess, sys
+    env = dict(os.environ); env["LZGPU_HELPER_MIN_ANCHORS"] = "0"
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(H.ROOT, "tests", "test_emul_gapped.py"),
+                        "-k", "golden_cases or obstacle_course"], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=1500)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_indexed_neighbour_search_equals_plain_walk(L):
     """msp_left_right with the running-max index vs the reference's walk, random snapshots (incl. > 64 overlaps)"""
     L.emul_selftest_neighbours.restype = C.c_int

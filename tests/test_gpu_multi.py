@@ -109,9 +109,9 @@ def test_a_rank_parses_only_what_it_owns_at_size(tmp_path):
 
 
 @needs_bins
-@pytest.mark.parametrize("fmt", ["maf", "axt", "general:name1,zstart1,end1,name2,strand2,zstart2,end2,score,cigarx", "cigar", "differences"])
+@pytest.mark.parametrize("fmt", ["maf", "axt", "general:name1,zstart1,end1,name2,strand2,zstart2,end2,score,cigarx", "cigar", "differences", "sam", "softsam"])
 def test_two_ranks_merge_line_oriented_formats(pair, fmt):
-    """the records of MAF / AXT / general / cigar / differences output, put back in file order by the unit markers
+    """the records of MAF / AXT / SAM / general / cigar / differences output, put back in file order by the unit markers
     (integration/lzgpu_shim.c::unit_marker), are the single process's and the pristine reference's byte for byte"""
     flags = ["--ydrop=9430", "--format=" + fmt]
     t, q = str(pair / "t.fa"), str(pair / "q.fa")
