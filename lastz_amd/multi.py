@@ -223,6 +223,17 @@ def merge_marked(texts, fmt="maf", rename=None):
     keys = [k for k, _ in allu]
     assert len(set(keys)) == len(keys), "a unit was produced by two ranks"
     allu.sort(key=lambda ku: ku[0])
+    if fmt.lstrip("~").startswith(("sam", "softsam")):
+        # the target's @SQ lines are printed once per process, when its first strand starts (src/sam.c:213-250) -- behind
+        # the rank's first unit marker: every rank's first block opens with them; the job has them once, behind @HD / @RG
+        sq = []
+        for i, (k, u) in enumerate(allu):
+            lines = u.splitlines(True)
+            mine = [l for l in lines if l.startswith("@SQ\t")]
+            if mine:
+                sq = sq or mine
+                allu[i] = (k, "".join(l for l in lines if not l.startswith("@SQ\t")))
+        head = (head or "") + "".join(sq)
     body = "".join(u for _, u in allu)
     if fmt.lstrip("~w").startswith("axt"):
         n = [-1]

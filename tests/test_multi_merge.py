@@ -97,14 +97,19 @@ def test_line_oriented_formats_merge_by_unit_markers():
     assert multi.merge_marked([m0, m1], "maf") == "##maf version=1\n" + m1.split("\n", 2)[2] + m0.split("\n", 2)[2]
     # a rank that produced nothing at all contributes its header only
     assert multi.merge_marked(["##maf version=1\n", m1], "maf") == "##maf version=1\n" + m1.split("\n", 2)[2]
+    # SAM: every rank prints the target's @SQ lines once, behind its first unit marker; the job has them once, behind @HD
+    s0 = "@HD\tVN:1.0\tSO:unsorted\n#lzgpu-unit 2 0\n@SQ\tSN:t\tLN:9\nqb\t0\tt\t1\t255\t5M\t*\t0\t0\tACGTA\t*\n"
+    s1 = "@HD\tVN:1.0\tSO:unsorted\n#lzgpu-unit 1 0\n@SQ\tSN:t\tLN:9\nqa\t0\tt\t2\t255\t5M\t*\t0\t0\tCGTAC\t*\n#lzgpu-unit 1 1\nqa\t16\tt\t3\t255\t5M\t*\t0\t0\tGTACG\t*\n"
+    assert multi.merge_marked([s0, s1], "sam") == ("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:t\tLN:9\nqa\t0\tt\t2\t255\t5M\t*\t0\t0\tCGTAC\t*\n"
+                                                    "qa\t16\tt\t3\t255\t5M\t*\t0\t0\tGTACG\t*\nqb\t0\tt\t1\t255\t5M\t*\t0\t0\tACGTA\t*\n")
 
 
 def test_formats_the_launcher_takes_and_refuses(tmp_path):
     t = tmp_path / "t.fa"; t.write_text(">t\nACGT\n")
     for ok in (["--format=maf"], ["--format=MAF-"], ["--axt"], ["--format=general:name1,start1,name2"], ["--format=general-"],
-               ["--format=cigar"], ["--format=differences"], []):
+               ["--format=cigar"], ["--format=differences"], ["--format=sam"], ["--format=softsam-"], []):
         multi.check_supported(str(t), ok)
         assert (multi.output_format(ok) == "lav") == (ok == [])
-    for bad in (["--format=sam"], ["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
+    for bad in (["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
         with pytest.raises(ValueError):
             multi.check_supported(str(t), bad)
