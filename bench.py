@@ -337,8 +337,14 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
         rec["k_scan_hits"] = {"avg_launch_ms": ms, "frac": cnt["bp_extended"] / prof["k_scan_hits"]["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if not do_gapped:
         return rec, last
-    # ---- the gapped stage of the same pair (configs[2]: --ydrop=9430)
     segs = [hsps_to_segs(lzgpu, h, rev) for rev, h in enumerate(last)]
+    # ---- N2, --chain: lzgpu_reduce_to_chain on the pair's HSPs, strand by strand (a host routine, in the reference and here:
+    # src/chain.c:497; the reference's own clock of it on this pair is in profiles/r04_chain_clock_cli_timing.txt)
+    c0 = time.perf_counter()
+    kept = [lib.reduce_to_chain(s)[0] for s in segs]
+    rec["chain"] = {"call": "lzgpu_reduce_to_chain per strand, default penalties (--chain)", "host_s": time.perf_counter() - c0,
+                    "anchors": int(len(segs[0]) + len(segs[1])), "kept": int(len(kept[0]) + len(kept[1])), "device": "none (host routine)"}
+    # ---- the gapped stage of the same pair (configs[2]: --ydrop=9430)
     probs = lambda: [dict(anchors=segs[slot].copy(), slot=slot, ydrop=9430) for slot in (0, 1)]
     lib.gapped_extend_batch(sub, probs())                                       # warm-up (allocations)
     # strand by strand, as the reference's host loop calls the stage (src/lastz.c:3401-3419) ...
@@ -477,7 +483,7 @@ def run_single(a, torch, lib):
         sha3, rows3 = hsp_rows_sha(l3)
         ns = {"workload": "BASELINE.json north_star size: synthetic 200000000 bp target vs 200000000 bp query, 12-of-19 seed + 1 transition, both strands; "
                           "1 warm-up + 2 timed steps of the seed stage, then the gapped stage (--ydrop=9430) as one batch",
-              **{k: r3[k] for k in ("ms_per_step", "value", "bp2_per_s", "hsps", "scan_mode", "counters_per_step", "kernel_ms_per_step", "roofline", "gapped")},
+              **{k: r3[k] for k in ("ms_per_step", "value", "bp2_per_s", "hsps", "scan_mode", "counters_per_step", "kernel_ms_per_step", "roofline", "gapped", "chain")},
               "parity": {"hsp_rows": rows3, "hsp_sha": sha3, "hsp_sha_ok": (sha3 == g2["hsp_sha"]) if g2 else None,
                          "alignments_ok": (r3["gapped"]["alignments"] == g2["lav_blocks"]) if g2 else None,
                          "reference": "tests/golden/bench200m.sha.json (pristine lastz 1.04.58 on this pair, tests/golden/make_bench200m_sha.py)" if g2 else
@@ -519,6 +525,8 @@ def run_single(a, torch, lib):
            "kernel_ms_per_step": rec["kernel_ms_per_step"], "roofline": rec["roofline"], "parity": parity}
     if gapped is not None:
         out["gapped"] = gapped
+    if "chain" in rec:
+        out["chain"] = rec["chain"]
     if cli is not None:
         out["cli"] = cli
     if ns is not None:

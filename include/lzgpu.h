@@ -274,6 +274,28 @@ int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n, lz_align**
                               uint32_t** ops, uint64_t* n_ops);
 
 /* ---- instrumentation (bench.py, tests) ---------------------------------------------------- */
+/* ---- N2: chaining (--chain) ------------------------------------------------------------------
+ * Replaces reduce_to_chain(st, diagPen, antiPen, scale, connect) (src/chain.c:497-615) with connect =
+ * chain_connect_penalty (src/lastz.c:3687-3741), as try_reduce_to_chain calls it for an unpartitioned pair
+ * (src/chain.c:248-250): the highest-scoring chain of the anchors under
+ *     chain[i] = scale * s_i + max(0, max over j with pos1_j < pos1_i and pos2_j < pos2_i of chain[j] - connect(j, i)).
+ * A HOST routine in the reference and here (each anchor needs the finished values of every earlier one):
+ * it needs no device and never touches one.  Which of several equally good predecessors wins follows the
+ * reference's K-d tree traversal, so the kept set is the reference's, not merely one of equal score.
+ *   diag_pen / anti_pen  : the tree's pruning bounds (the reference passes chainDiag / chainAnti for them)
+ *   chain_diag/chain_anti: the connection penalty per diagonal / per anti-diagonal step
+ *   overlap_sub          : scoring->sub[rowChars[0]][colChars[0]], charged (times scale) per overlapped base
+ * On return *kept = malloc'd indices INTO segs of the chain's members in the order the reference leaves them in the
+ * table (qSegmentsByPos1, src/segment.c:1657), *n_kept their number, *best the chain's score (rounded and clipped like
+ * src/chain.c:598-606, integer scores).  Free *kept with lzgpu_free.  Integer score builds only (score_type I). */
+typedef struct lz_chain_args {
+    int32_t diag_pen, anti_pen;
+    int32_t chain_diag, chain_anti;
+    int32_t scale;                 /* chainScale = 100 (src/lastz.c:318)                           */
+    int32_t overlap_sub;
+} lz_chain_args;
+int lzgpu_reduce_to_chain(const lz_chain_args* a, const lz_segment* segs, uint32_t n, uint32_t** kept, uint32_t* n_kept, int32_t* best);
+
 typedef struct lz_counters {       /* same events as the reference's collect_stats build          */
     uint64_t words;                /* "words in seq 2"    src/seed_search.c:514                   */
     uint64_t raw_hits;             /* "raw seed hits"     src/seed_search.c:865                   */

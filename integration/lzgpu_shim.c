@@ -56,6 +56,7 @@ u64       ref_write_capsule_file (FILE* f, char* filename, seq* seq, u8* revNucs
 u32       ref_quantum_seed_hit_search (seq* seq1, postable* pt, seq* seq2, unspos start, unspos end,
                                        const s8 charToBits[], seed* hitSeed, scoreset* scoring, score ballScore,
                                        hitprocessor processor, void* processorInfo);
+score     ref_try_reduce_to_chain (seq* seq1, seq* seq2, segtable* st, score diagPen, score antiPen, int scale, chainer connect);
 alignel*  ref_tweener_interpolate (alignel* a, seq* seq1, seq* seq2, int selfCompare, int inhibitTrivial,
                                    const s8 charToBits[], seed* tweenSeed, scoreset* scoring, scoreset* maskedScoring,
                                    tback* tb, score xDrop, int gappedAllBounds, score yDrop, int trimToPeak, score scoreThresh,
@@ -666,6 +667,80 @@ alignel* gapped_extend
 	}
 	note ("gapped", "done on the GPU");
 	return head;
+	}
+
+/* ---- N2: chaining ---- */
+
+/* The library's routine takes the connection penalty as chain_connect_penalty's three constants (src/lastz.c:3687-3741);
+ * the reference hands over a callback.  The constants are read off the callback with three probe pairs and the closed
+ * form is checked against it on a fourth; a callback that is anything else goes to the reference's routine. */
+static int chain_constants (chainer connect, score diagPen, score antiPen, int scale, lz_chain_args* a)
+	{
+	segment p, q;
+	long long v;
+	memset (&p, 0, sizeof(p));  memset (&q, 0, sizeof(q));
+	p.pos1 = 100;  p.pos2 = 100;  p.length = 10;               /* ends at 109 / 109 */
+	q.length = 10;
+	q.pos1 = 107;  q.pos2 = 107;                               /* same diagonal, 3 bases overlap */
+	v = (*connect) (&p, &q, scale);
+	if ((scale <= 0) || (v % (3LL * scale) != 0)) return false;
+	a->overlap_sub = (int32_t) (v / (3LL * scale));
+	q.pos1 = 120;  q.pos2 = 110;                               /* 10 diagonals below, no bases between in seq 2 */
+	v = (*connect) (&p, &q, scale);
+	if (v % 10 != 0) return false;
+	a->chain_diag = (int32_t) (v / 10);
+	q.pos1 = 110;  q.pos2 = 117;                               /* 7 diagonals above (|d|*diag), no bases between in seq 1; then 5 more */
+	v = (*connect) (&p, &q, scale);
+	if (v != 7LL * a->chain_diag) return false;
+	q.pos1 = 115;  q.pos2 = 122;
+	v = (*connect) (&p, &q, scale) - 7LL * a->chain_diag;
+	if (v % 5 != 0) return false;
+	a->chain_anti = (int32_t) (v / 5);
+	q.pos1 = 141;  q.pos2 = 118;                               /* the check: 23 diagonals, 8 bases */
+	if ((*connect) (&p, &q, scale) != 23LL * a->chain_diag + 8LL * a->chain_anti) return false;
+	q.pos1 = 105;  q.pos2 = 111;                               /* and: 6 diagonals the other way, 5 bases overlap in seq 1 */
+	if ((*connect) (&p, &q, scale) != 6LL * a->chain_diag + 5LL * scale * a->overlap_sub) return false;
+	a->diag_pen = diagPen;  a->anti_pen = antiPen;  a->scale = scale;
+	return true;
+	}
+
+score try_reduce_to_chain
+   (seq* seq1, seq* seq2, segtable* st, score diagPen, score antiPen, int scale, chainer connect)
+	{
+	lz_chain_args a;
+	lz_segment*   segs;
+	segment*      keep;
+	uint32_t*     kept = NULL;
+	uint32_t      nKept = 0, ix;
+	int32_t       best = 0;
+	int           rc;
+
+	if ((seq1->partition.p != NULL) || (seq2->partition.p != NULL)     /* (batches per partition: src/chain.c:252-470) */
+	 || (st == NULL) || (st->len == 0) || (!chain_constants (connect, diagPen, antiPen, scale, &a)))
+		{ note ("chain", "reference path");
+		  return ref_try_reduce_to_chain (seq1, seq2, st, diagPen, antiPen, scale, connect); }
+
+	segs = (lz_segment*) malloc_or_die ("lzgpu try_reduce_to_chain", ((size_t) st->len) * sizeof(lz_segment));
+	for (ix=0 ; ix<st->len ; ix++)
+		{
+		segs[ix].pos1 = st->seg[ix].pos1;  segs[ix].pos2   = st->seg[ix].pos2;
+		segs[ix].s    = st->seg[ix].s;     segs[ix].length = st->seg[ix].length;
+		segs[ix].id   = st->seg[ix].id;
+		}
+	rc = lzgpu_reduce_to_chain (&a, segs, st->len, &kept, &nKept, &best);
+	free (segs);
+	if (rc < 0) suicidef ("lzgpu_reduce_to_chain: %s", lzgpu_last_error());
+	if (rc > 0)
+		{ note ("chain", "declined, reference path");
+		  return ref_try_reduce_to_chain (seq1, seq2, st, diagPen, antiPen, scale, connect); }
+
+	keep = (segment*) malloc_or_die ("lzgpu try_reduce_to_chain", ((size_t) nKept + 1) * sizeof(segment));
+	for (ix=0 ; ix<nKept ; ix++) keep[ix] = st->seg[kept[ix]];
+	for (ix=0 ; ix<nKept ; ix++) { st->seg[ix] = keep[ix];  st->seg[ix].filter = false; }
+	st->len = nKept;
+	free (keep);  lzgpu_free (kept);
+	note ("chain", "done by the library");
+	return best;
 	}
 
 /* ---- the tweener ---- */

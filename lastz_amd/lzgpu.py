@@ -69,7 +69,7 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_device
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch", "lzgpu_window_search",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window", "lzgpu_dp_longest",
-           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode"]
+           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode", "lzgpu_reduce_to_chain"]
 
 
 class LzGpuError(RuntimeError):
@@ -305,6 +305,22 @@ class Lib:
         out = (C.c_void_p * n)(); no = (C.c_uint64 * n)(); ops = (C.c_void_p * n)(); nops = (C.c_uint64 * n)()
         self._check(self.L.lzgpu_gapped_extend_batch(arr, n, out, no, ops, nops), "lzgpu_gapped_extend_batch")
         return [self._gapped_out(self.L, out[k], no[k], ops[k], nops[k]) for k in range(n)]
+
+    # ---- N2: chaining (host routine of the library; needs no device)
+    def reduce_to_chain(self, anchors, chain_diag=0, chain_anti=0, scale=100, overlap_sub=91, diag_pen=None, anti_pen=None):
+        """anchors: SEG_DTYPE array of one (query, strand) -> (indices of the chain's members in the reference's order, chain score);
+        src/chain.c:497 with chain_connect_penalty (src/lastz.c:3687); overlap_sub = sub[rowChars[0]][colChars[0]]"""
+        anchors = np.ascontiguousarray(anchors, dtype=SEG_DTYPE)
+        a = (C.c_int32 * 6)(chain_diag if diag_pen is None else diag_pen, chain_anti if anti_pen is None else anti_pen,
+                            chain_diag, chain_anti, scale, overlap_sub)
+        kept = C.c_void_p(); n = C.c_uint32(); best = C.c_int32()
+        self._check(self.L.lzgpu_reduce_to_chain(a, _ptr(anchors), C.c_uint32(len(anchors)), C.byref(kept), C.byref(n), C.byref(best)),
+                    "lzgpu_reduce_to_chain")
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            C.memmove(out.ctypes.data, kept, 4 * n.value)
+        self.L.lzgpu_free(kept)
+        return out, best.value
 
     # ---- B1 + B2 of many windows (N3)
     def window_search(self, masked_sub, windows, sd, ctb, q=None, slot=-1, xdrop=910, hsp_threshold=3000):

@@ -72,7 +72,7 @@ CASES = [
     ("axt", [T + "pseudocat.fa", T + "pseudopig.fa", "--format=axt"], "base_test.default.axt", "axt", None,
      {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}, "gapped": {"done on the GPU": 6}}),
     ("chained", [T + "pseudocat.fa", T + "pseudopig.fa", "C=1", "W=8", "T=0"], "base_test.chained.lav", "lav", None,
-     {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}}),
+     {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}, "chain": {"done by the library": 6}}),
     ("extended", [T + "pseudocat.fa", T + "pseudopig.fa", "C=2", "W=8", "T=0"], "base_test.extended.lav", "lav", None,
      {"table": {"built on the GPU": 1}, "search": {"done on the GPU": 6}, "gapped": {"done on the GPU": 6}}),
     ("interpolated", [T + "pseudocat.fa", T + "pseudopig.fa", "C=2", "W=8", "T=0", "H=2200"], "base_test.interpolated.lav", "lav", None,
@@ -144,7 +144,7 @@ def test_base_test(sandbox, name, args, golden, how, stdin, expect):
     # whatever ran, nothing failed over silently: every stage line is one of the known outcomes
     known = {"built on the GPU", "done on the GPU", "reference path", "declined, reference path", "loaded from the table cache",
              "copied to the host for a reference routine", "unit of another rank", "shared with the other ranks", "received from rank 0",
-             "windows searched on the GPU", "windows extended on the GPU", "no windows"}
+             "windows searched on the GPU", "windows extended on the GPU", "no windows", "done by the library"}
     assert all(h in known for st in seen.values() for h in st), seen
 
 

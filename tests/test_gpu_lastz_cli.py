@@ -39,7 +39,7 @@ def run(binary, args, cwd, env_extra=None):
 CASES = [("base_test.default.lav", [], {"table": 1, "search": 6, "gapped": 6}),
          ("base_test.hsp.lav", ["C=3", "W=8", "T=0"], {"table": 1, "search": 6}),
          ("base_test.extended.lav", ["C=2", "W=8", "T=0"], {"table": 1, "search": 6}),
-         ("base_test.chained.lav", ["C=1", "W=8", "T=0"], {"table": 1, "search": 6}),
+         ("base_test.chained.lav", ["C=1", "W=8", "T=0"], {"table": 1, "search": 6, "chain": 6}),
          ("base_test.interpolated.lav", ["C=2", "W=8", "T=0", "H=2200"], {"table": 1, "search": 6}),     # tweener second pass
          ("base_test.hits.lav", ["W=8", "T=0", "--plus", "--nogfextend", "--nogapped"], {"table": 1})]
 
@@ -53,7 +53,7 @@ def test_reference_command_lines(sandbox, golden, flags, on_gpu):
     assert normalize_lav(out) == normalize_lav(want)
     for stage, n in on_gpu.items():                 # the GPU path really ran (no quiet reference fallback)
         assert err.count(f"[lzgpu] {stage}: ") >= n
-        assert err.count(f"[lzgpu] {stage}: done on the GPU") + err.count(f"[lzgpu] {stage}: built on the GPU") >= n, err[-1500:]
+        assert err.count(f"[lzgpu] {stage}: done on the GPU") + err.count(f"[lzgpu] {stage}: built on the GPU") + err.count(f"[lzgpu] {stage}: done by the library") >= n, err[-1500:]
 
 
 @needs_bins
@@ -69,6 +69,23 @@ def test_same_bytes_as_pristine_binary(sandbox, fmt):
     strip = (lambda s: normalize_lav(s)) if fmt == "lav" else (lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#")))
     assert strip(a) == strip(b)
     assert len(a) > 2000
+
+
+@needs_bins
+@pytest.mark.parametrize("chain", ["--chain", "--chain=20,20", "--chain=400,3", "--chain=3,400"])
+def test_chaining_by_the_library(sandbox, chain):
+    """N2: try_reduce_to_chain of the bound binary is the library's host routine (lastz_amd/csrc/lz_chain_host.cpp); HSPs of the GPU
+    search in, chain out, gapped extension of the chain on the GPU: the pristine binary's bytes"""
+    t, q = seqio.synth_pair(2_000_000, 2_000_000, seed=43)
+    q[300_000:420_000] = q[900_000:1_020_000]                   # a duplication: competing off-diagonal HSPs
+    seqio.write_fasta(sandbox / "tc.fa", [("target", t)]); seqio.write_fasta(sandbox / "qc.fa", [("query", q)])
+    for tail in (["--nogapped", "--format=general-:start1,end1,start2,end2,strand2,score"], ["--ydrop=9430", "--format=axt"]):
+        args = ["tc.fa", "qc.fa", chain] + tail
+        a, err = run(GPU_BIN, args, sandbox, {"LZGPU_VERBOSE": "1"})
+        b, _ = run(REF_BIN, args, sandbox)
+        assert err.count("[lzgpu] chain: done by the library") == 2 and "[lzgpu] chain: reference path" not in err, err[-1500:]
+        strip = lambda s: "\n".join(l for l in s.split("\n") if not l.startswith("#"))
+        assert strip(a) == strip(b) and len(a) > 2000
 
 
 @needs_bins

@@ -12,6 +12,7 @@ import json
 d = json.load(open("$O/bench.json"))
 print("ms/step", round(d["ms_per_step"],1), "frac", round(d["roofline"]["frac"],3), {k: v for k, v in d["parity"].items() if k.endswith("_ok")})
 if "gapped" in d: print("gapped", {k: d["gapped"][k] for k in ("wall_s","gcups_wall","k_ydrop_ms","alignments_ok")}, d["gapped"]["longest_dp"]["cycles_per_row"])
+if "chain" in d: print("chain", d["chain"])
 if "cli" in d: print("cli", d["cli"]["runs_s"])
 if "content" in d: print("content", {k: (round(v["ms_per_step"],1), v["scan_mode"], round(v["k_scan_hits"]["frac"],3)) for k, v in d["content"].items()})
 ns = d.get("north_star")
