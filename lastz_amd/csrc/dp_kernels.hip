@@ -125,8 +125,9 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         cand_wave_max = __builtin_amdgcn_readlane(inc, 63);     // (reduce_row wants the same maximum: the candidates do not change in walk 3)
         if (wl == 63) sh.wc[w] = inc;
         __syncthreads();
-        s32 pre = b0;
-        for (int j = 0; j < w; j++) if (sh.wc[j] > pre) pre = sh.wc[j];
+        s32 pre = b0;                                           // (all partials in one read; w is a scalar: selects, no loop)
+#pragma unroll
+        for (int j = 0; j < LZ_DP_WAVES - 1; j++) { const s32 v = sh.wc[j]; if (j < w && v > pre) pre = v; }
         regs.run_in = ex > pre ? ex : pre;
     }
     __device__ __forceinline__ void reduce_row(LzDpSharedBase& sh)

@@ -151,9 +151,11 @@ struct LzDpSharedBase {
     // what lane 0 publishes for the other lanes before each row (its own sweep state is LzDpCtl): sixteen words,
     // written together at the end of the lane-0 step and read together behind its barrier (four 128-bit LDS
     // accesses each way instead of sixteen / ten scattered ones)
+    // (the first eight are what every row needs: two 128-bit reads, issued together, BEFORE any branch on them -- a read
+    // behind a branch behind a read is an LDS round trip each, ~100 cycles for a wave that has its SIMD to itself)
     alignas(16) u32 row; u32 LY, ry_iter, cpl;
-    s32 best; u32 trow_cur, n_act, done;
-    u32 extra, fill_n, fill_base, fill_trow;              // work for all lanes before the next row
+    s32 best; u32 trow_cur, done, extra;
+    u32 n_act, fill_n, fill_base, fill_trow;              // work for all lanes before the next row
     u32 stage_lo, stage_a; s32 fill_i; u32 b_hi;
     u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
     // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
@@ -189,6 +191,9 @@ struct LzDpLane {                       // per-lane values carried between the s
     u32 first, last;                    // first / last live column of the block (0xFFFFFFFF: none)
     s32 bnd; u32 bnd_row, bnd_col, bnd_has;   // no_trim: the lane's best diagonal-won live cell on row M / column N, the latest on ties
     u32 tb_v;                           // traceback: the link this lane of the leading wave fetched for the window
+    // the lane's first LZ_DP_BATCH cells, carried from walk to walk (with two columns per lane -- rows up to 512 wide --
+    // that is the whole block: walk 2 and walk 3 then read nothing from the sweep row)
+    s32 k_cc[2], k_dd[2], k_sc[2]; u32 k_mk[2], k_lk[2];
 };
 // Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
 // test harness); their semantics are fixed here:
@@ -475,7 +480,10 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     bool swept = false;
     u64 tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
     u64 tl[5] = { 0, 0, 0, 0, 0 };
-    while (!(REPL ? x.uni(ct.done) : sh.done)) {
+    // (whether the sweep is over is known from the read behind the serial piece: the loop test reads nothing)
+    bool finished = REPL ? x.uni(ct.done) != 0u : sh.done != 0u;
+    u32 arow_next = 0;                                          // the A class of the NEXT row, fetched a row ahead (behind walk 3's reads)
+    while (!finished) {
         const u64 ts = LZ_PHASE_CLOCK();
         // (published at the end, in one block -- or, REPL, simply kept)
         u32 p_fill_n = 0, p_fill_base = 0, p_fill_trow = 0, p_stage_lo = ct.b_hi, p_stage_a = 0, p_trow_cur = 0, p_ry_iter = 0, p_cpl = 0, p_extra = 0;
@@ -554,8 +562,8 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             }();
             if (!REPL) {
                 sh.row = ct.row; sh.LY = ct.LY; sh.ry_iter = p_ry_iter; sh.cpl = p_cpl;
-                sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.n_act = ct.n_act; sh.done = ct.done;
-                sh.extra = p_extra; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
+                sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.done = ct.done; sh.extra = p_extra;
+                sh.n_act = ct.n_act; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
                 sh.stage_lo = p_stage_lo; sh.stage_a = p_stage_a; sh.fill_i = p_fill_i; sh.b_hi = ct.b_hi;
             }
             const u64 q5 = LZ_PHASE_CLOCK();
@@ -563,9 +571,20 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += q5 - q4;
         };
         if (REPL) x.every_wave(control); else x.leader(control);
-        if (REPL ? x.uni(ct.done) != 0u : sh.done != 0u) break;
+        u32 e_on, n_act_now = 0;
+        if (REPL) {
+            finished = x.uni(ct.done) != 0u; e_on = p_extra;
+            row = x.uni(ct.row); LY0 = x.uni(ct.LY); RYi = x.uni(p_ry_iter); cpl = x.uni(p_cpl); best0 = x.uni(ct.best); trow_cur = x.uni(p_trow_cur);
+        } else {
+            // the published words of every row, read together (two 128-bit reads and one wait), then the branches
+            const u32 v_row = sh.row, v_ly = sh.LY, v_ry = sh.ry_iter, v_cpl = sh.cpl, v_trow = sh.trow_cur, v_done = sh.done, v_extra = sh.extra;
+            const s32 v_best = sh.best;
+            if (BOUNDS) n_act_now = sh.n_act;
+            finished = x.uni(v_done) != 0u; e_on = x.uni(v_extra);
+            row = x.uni(v_row); LY0 = x.uni(v_ly); RYi = x.uni(v_ry); cpl = x.uni(v_cpl); best0 = x.uni(v_best); trow_cur = x.uni(v_trow);
+        }
+        if (finished) break;
         // the rare parallel pieces of the row set-up: a long run of overhang cells, the next columns' / rows' classes
-        const u32 e_on = REPL ? p_extra : sh.extra;
         if (e_on) {
             const u32 e_fill_n = REPL ? p_fill_n : sh.fill_n, e_fill_base = REPL ? p_fill_base : sh.fill_base, e_fill_trow = REPL ? p_fill_trow : sh.fill_trow;
             const s32 e_fill_i = REPL ? p_fill_i : sh.fill_i;
@@ -584,31 +603,36 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 }
             });
         }
-        if (REPL) { row = x.uni(ct.row); LY0 = x.uni(ct.LY); RYi = x.uni(p_ry_iter); cpl = x.uni(p_cpl); best0 = x.uni(ct.best); trow_cur = x.uni(p_trow_cur); }
-        else { row = x.uni(sh.row); LY0 = x.uni(sh.LY); RYi = x.uni(sh.ry_iter); cpl = x.uni(sh.cpl); best0 = x.uni(sh.best); trow_cur = x.uni(sh.trow_cur); }
         swept = true;
-        const bool any_active = BOUNDS && sh.n_act != 0;
+        const bool any_active = BOUNDS && (REPL ? ct.n_act : n_act_now) != 0;
         const u32 row_stamp = SH::stamp(row);
-        const u32 arow = sh.aa[(row - 1) & (LZ_DP_LANES - 1)];
+        // the row's A class: fetched during the previous row (arow_next) unless this row opens a freshly staged block of aa[]
+        const u32 aidx = (row - 1) & (LZ_DP_LANES - 1);
+        const u32 arow = aidx == 0 ? x.uni((u32)sh.aa[0]) : arow_next;
         const s32* trow_tab = tab + (arow << 5);
 
         // The walks read the sweep row in batches of LZ_DP_BATCH cells: all LDS reads of a batch are
         // issued before the serial recurrence consumes them (one wave per SIMD has nothing else to
-        // hide LDS latency behind).
+        // hide LDS latency behind).  A lane's FIRST batch is read once, by walk 1, and carried in registers
+        // (LzDpLane::k_*) through walks 2 and 3.
+        auto load_batch = [&](u32 base, s32* vcc, s32* vdd, s32* vsc, u32* vmk) {
+            u32 vbb[LZ_DP_BATCH];
+            LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
+                const u32 rx = LZ_RING(base + k);
+                vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
+            }
+            LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
+        };
         // walk 1: block summaries of the insertion recurrence
         const u64 ta = LZ_PHASE_CLOCK();
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
-            r.c_left_old = (c0 < RYi && c0 > LY0) ? sh.cc[LZ_RING(c0 - 1)] : LZ_DP_NEGINF;
+            const s32 cl = sh.cc[LZ_RING(c0 - 1u)];             // (unconditional: issued with the batch's reads; selected below)
+            load_batch(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
+            r.c_left_old = (c0 < RYi && c0 > LY0) ? cl : LZ_DP_NEGINF;
             s32 c_left = r.c_left_old;
-            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
-                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH];
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
-                    const u32 rx = LZ_RING(base + k);
-                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
-                }
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
+            auto cells = [&](u32 base, const s32* vcc, const s32* vdd, const s32* vsc, const u32* vmk) {
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
                     if (col < c1) {
@@ -625,6 +649,12 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                         }
                     }
                 }
+            };
+            cells(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
+            for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH];
+                load_batch(base, vcc, vdd, vsc, vmk);
+                cells(base, vcc, vdd, vsc, vmk);
             }
             r.A = A; r.K = K; r.cut = cut;
         });
@@ -637,13 +667,8 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
-            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
-                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vbb[LZ_DP_BATCH], vlk[LZ_DP_BATCH];
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
-                    const u32 rx = LZ_RING(base + k);
-                    vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
-                }
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
+            // one batch: the new C, D and links replace the old values in vcc / vdd / vlk
+            auto cells = [&](u32 base, s32* vcc, s32* vdd, const s32* vsc, const u32* vmk, u32* vlk) {
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
                     vlk[k] = 0;
@@ -674,6 +699,12 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                     const u32 col = base + k;
                     if (col < c1) { const u32 rx = LZ_RING(col); sh.cc[rx] = vcc[k]; sh.dd[rx] = vdd[k]; sh.lk[rx] = (u8)vlk[k]; }
                 }
+            };
+            cells(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk, r.k_lk);  // (k_cc / k_lk go on to walk 3)
+            for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vlk[LZ_DP_BATCH];
+                load_batch(base, vcc, vdd, vsc, vmk);
+                cells(base, vcc, vdd, vsc, vmk, vlk);
             }
             r.cand = cmax; r.cand_col = ccol;
         });
@@ -681,14 +712,13 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         x.scan_cand(sh, best0);
         const u64 tc = LZ_PHASE_CLOCK();
         // walk 3: prune test against the running best, final stores, traceback bytes
+        const u32 a_nx = sh.aa[row & (LZ_DP_LANES - 1)];        // (next row's A class: not used when that row opens a new block)
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
             u8* tbr = tb + (u32)(trow_cur + c0);
-            for (u32 base = c0; base < c1; base += LZ_DP_BATCH) {
-                s32 vcc[LZ_DP_BATCH]; u32 vlk[LZ_DP_BATCH];
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) { const u32 rx = LZ_RING(base + k); vcc[k] = sh.cc[rx]; vlk[k] = sh.lk[rx]; }
+            auto cells = [&](u32 base, const s32* vcc, const u32* vlk) {
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
                     if (col < c1) {
@@ -711,10 +741,17 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                     }
                 }
                 tbr += LZ_DP_BATCH;
+            };
+            cells(c0, r.k_cc, r.k_lk);
+            for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
+                s32 vcc[LZ_DP_BATCH]; u32 vlk[LZ_DP_BATCH];
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) { const u32 rx = LZ_RING(base + k); vcc[k] = sh.cc[rx]; vlk[k] = sh.lk[rx]; }
+                cells(base, vcc, vlk);
             }
             r.first = first; r.last = last;
         });
         x.reduce_row(sh);
+        arow_next = x.uni(a_nx);
         const u64 td = LZ_PHASE_CLOCK();
         tp0 += ta - ts; tp1 += tb_ - ta; tp2 += tc - tb_; tp3 += td - tc;
     }
