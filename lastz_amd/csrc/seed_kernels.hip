@@ -24,6 +24,19 @@
 // ------------------------------------------------------------------------------------------
 // byte -> code translation (one pass per sequence; the table folds charToBits and the score
 // class of the byte, see lz_common.hpp)
+// The per-hit streams of the stage -- keys, partition bytes, summaries, records: written once by one kernel, read once by the
+// next, 8-21 bytes per hit and 4-62 G hits per step -- are stored and loaded NON-TEMPORALLY, so that they pass through L2 and the
+// 256 MiB memory-side cache without pushing out what IS re-read: the position table's lists, the target's and the query's 2-bit
+// windows.  Measured (same box, A/B against -DLZ_NO_NT): at 200 Mbp x 200 Mbp fill 360 -> 318, scans 1260 -> 1253, tasks 87 -> 80 ms
+// per step (-2.1 % of the step); on the 50 Mbp pair -1 ms.  k_partition keeps plain accesses: with non-temporal ones it ran
+// 10-15 % slower (its 512-byte runs per partition want to merge in L2).
+#if defined(LZ_NO_NT)
+#define LZ_NT_LD(p_) (*(p_))
+#define LZ_NT_ST(v_, p_) (*(p_) = (v_))
+#else
+#define LZ_NT_LD(p_) __builtin_nontemporal_load(p_)
+#define LZ_NT_ST(v_, p_) __builtin_nontemporal_store((v_), (p_))
+#endif
 __global__ void __launch_bounds__(LZ_TPB)
 k_encode(const u8* __restrict__ raw, u8* __restrict__ code, u32 len, const u8* __restrict__ cls)
 {
@@ -538,7 +551,7 @@ k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (ok[k]) { const u64 kk = lz_hit_key(p1[k], p2[k]); keys[dst[k]] = kk; bins[dst[k]] = (u8)LZ_KEY_BIN(kk); }
+                    if (ok[k]) { const u64 kk = lz_hit_key(p1[k], p2[k]); LZ_NT_ST(kk, keys + dst[k]); LZ_NT_ST((u8)LZ_KEY_BIN(kk), bins + dst[k]); }
             }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
         }
@@ -828,7 +841,7 @@ __device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzL
         }
         my_n += (u32)__popcll(mm);
     }
-    if (valid && !queued) summ[idx] = lz_lut_summary(L, R, P.min_score);
+    if (valid && !queued) LZ_NT_ST(lz_lut_summary(L, R, P.min_score), summ + idx);
 }
 template <bool SP>
 __device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzLutRaw<SP>& rawl, LzLutRaw<SP>& rawr)
@@ -918,8 +931,9 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
         auto load_keys = [&](u64 sp, u64& a0, u64& a1, u64& a2, u64& a3) {
             const u64 base = sp * SPAN;
             const u32 sn = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
-            a0 = (lane < sn) ? keys[base + lane] : 0ull;               a1 = (lane + 64u < sn) ? keys[base + lane + 64u] : 0ull;
-            a2 = (lane + 128u < sn) ? keys[base + lane + 128u] : 0ull; a3 = (lane + 192u < sn) ? keys[base + lane + 192u] : 0ull;
+#define LZ_KEY_LD(p_) LZ_NT_LD(p_)
+            a0 = (lane < sn) ? LZ_KEY_LD(keys + base + lane) : 0ull;               a1 = (lane + 64u < sn) ? LZ_KEY_LD(keys + base + lane + 64u) : 0ull;
+            a2 = (lane + 128u < sn) ? LZ_KEY_LD(keys + base + lane + 128u) : 0ull; a3 = (lane + 192u < sn) ? LZ_KEY_LD(keys + base + lane + 192u) : 0ull;
         };
         u64 k0, k1, k2, k3;
         load_keys(span, k0, k1, k2, k3);
@@ -966,7 +980,7 @@ k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut
             LzLutScan L = t.L, R = t.R;
             while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SP>(Q, lut, t.diag, L, ctab);
             while (R.alive == 1 && R.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<true, SP>(Q, lut, t.diag, R, ctab);
-            summ[t.idx] = lz_lut_summary(L, R, P.min_score);
+            LZ_NT_ST(lz_lut_summary(L, R, P.min_score), summ + t.idx);
         }
     }
 }
@@ -1001,7 +1015,7 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
 #pragma unroll
     for (u32 r = 0; r < LZ_PP_ROUNDS; r++) {
         const bool v = l0 + 64u * r < tile_n;
-        kk[r] = v ? keys[base + l0 + 64u * r] : 0ull;
+        kk[r] = v ? keys[base + l0 + 64u * r] : 0ull;             // (plain loads and stores here: non-temporal ones made this kernel 10-15 % slower)
         ss[r] = v ? summ[base + l0 + 64u * r] : 0u;
     }
     __syncthreads();
@@ -1289,7 +1303,7 @@ k_settle2(LzExtendParams P, const u64* __restrict__ recs, const u32* __restrict_
 #pragma unroll
         for (int rr = 0; rr < LZ_S2_ROUNDS; rr++) {
             const u64 li = (u64)tt * LZ_S2_TILE + sw * (64u * LZ_S2_ROUNDS) + (u32)rr * 64u + lane;
-            x[rr] = (tt < ntiles && li < (u64)n) ? recs[(size_t)r0 + li] : ~0ull;       // ~0: no record
+            x[rr] = (tt < ntiles && li < (u64)n) ? LZ_NT_LD(recs + (size_t)r0 + li) : ~0ull;       // ~0: no record
         }
     };
     auto count_tile = [&](u32 tt, const u64* x, u32* slot) {    // ranks inside (wave, bucket) -> slot[], totals -> cnt[tt & 1][sw][]
