@@ -155,7 +155,8 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 };
 
 #ifndef LZ_DP_WPE
-#define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow: six DPs of four waves per CU
+#define LZ_DP_WPE 5                    // waves per SIMD the register allocation must allow: five DPs of four waves per CU (six fit the LDS, but at 80
+                                       // registers the kernel with bounds spilled 15-44 of them once the walks carried their cells in registers)
 #endif
 #ifndef LZ_DP_WPE_FREE
 #define LZ_DP_WPE_FREE 7               // ... and seven of the problems without earlier alignments (no mask stamps: 22 KiB per DP)
