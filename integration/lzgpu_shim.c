@@ -107,9 +107,10 @@ __attribute__((constructor)) static void unlocked_stdout (void)
 	if (getenv ("LZGPU_LOCKED_STDIO") == NULL) __fsetlocking (stdout, FSETLOCKING_BYCALLER);
 	/* lastz is a process that lives a second or two.  The library's default of 2^31 hits per chunk (a 50 Mbp strand in
 	 * one chunk) means 41 GiB of chunk buffers; what a process frees at exit the driver clears before it hands it out
-	 * again, and lastz runs back to back then wait for that: 3 of 8 runs of the 50 Mbp pair took 3.1 s instead of
-	 * 1.35 s (a 1.8 s hipMalloc).  With chunks of 2^30 (20 GiB) none did, at 3 ms more per search. */
-	if (getenv ("LZGPU_HIT_CAPACITY") == NULL) lzgpu_set_hit_capacity (1ull << 30);
+	 * again, and lastz runs back to back then wait for that: with chunks of 2^30 (20 GiB) the first two runs on a fresh box
+	 * spent 1.0 and 0.8 s in hipMalloc (2.3 and 2.1 s wall instead of 1.32) and every fourth run of a series 4.3 s.  Chunks
+	 * of 2^28 (5.6 GiB) cost 15 ms more per search and bound that wait at a quarter (tools/cli_caps.sh, round 4). */
+	if (getenv ("LZGPU_HIT_CAPACITY") == NULL) lzgpu_set_hit_capacity (1ull << 28);
 	}
 
 /* a clock line without a note: entry points of the stages, for tools/cli_prof.sh */

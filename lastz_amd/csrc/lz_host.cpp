@@ -230,70 +230,98 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
 {
     out.clear();
     if (order_out) order_out->clear();
-    std::vector<RecKey> order(n_rec);
-    for (u32 i = 0; i < n_rec; i++) {
-        u32 pt = 0, pq = 0, probe = 0;
-        if (match_counts) probe = match_counts[5 * (size_t)i + 4];
-        else {
-            if (!host_window_word(thost, recs[i].seed_pos1, sd, ctb, pt) ||
-                !host_window_word(qhost, recs[i].seed_pos2, sd, ctb, pq)) return LZGPU_ERR_STATE;
-            u32 x = pt ^ pq;
-            for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break;
-        }
-        if (probe >= (u32)sd.nprobes) return LZGPU_ERR_STATE;
-        order[i] = { ((u64)recs[i].seed_pos2 << 32) | probe, ~recs[i].seed_pos1, i };
-    }
-    // The GPU is idle while this runs (the call is synchronous): up to 16 threads, started ONCE, go through the
-    // phases together (sort of the chunks, log2(T) levels of pairwise merges, entropy factors) with a spin barrier
-    // between them.  (Round 2: four threads, started anew for every phase: 3.8 ms per search of the 50 Mbp pair,
-    // 4.6 % of the bench step.)
+    // The GPU is idle while this runs (the call is synchronous).  Up to sixteen threads of a pool that lives as long as the
+    // library go through four passes: keys + a count per (part, range of query positions); the keys dealt out into the ranges
+    // and each range sorted on its own (the order is by query position first: ranges, not merges -- the last level of a merge
+    // tree is one thread merging everything); entropy factors and survivors counted; output.
+    // (Round 2: four threads started anew for every phase, 3.8 ms per search of the 50 Mbp pair; round 3: up to sixteen
+    // started once per call, chunk sorts + three levels of merges, 2.2-2.8 ms.)
     auto less = [](const RecKey& x, const RecKey& y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; };
+    static ForkJoin pool([]() { const u32 hw = std::thread::hardware_concurrency(); return hw >= 32 ? 15u : hw >= 16 ? 7u : hw >= 8 ? 3u : hw >= 4 ? 1u : 0u; }());
+    static std::mutex pool_m;                                   // (one search at a time uses it)
+    std::unique_lock<std::mutex> pool_lock(pool_m, std::defer_lock);
     u32 T = 1;
-    if (n_rec >= 16384) { const u32 hw = std::thread::hardware_concurrency(); T = hw >= 32 ? 16u : hw >= 8 ? 8u : hw >= 4 ? 4u : 1u; }
+    if (n_rec >= 16384) { pool_lock.lock(); T = pool.threads() + 1u; }
     auto part = [&](u32 t) { return (u32)((u64)n_rec * t / T); };
     const s32 zero_thresh = K > 0 ? K : 0;                      // src/lastz.c:2937-2939
+    u32 max_p2 = 0;
+    for (u32 i = 0; i < n_rec; i++) if (recs[i].seed_pos2 > max_p2) max_p2 = recs[i].seed_pos2;
+    const u32 R = T;                                            // ranges of query positions, about n_rec / T records each on even data
+    auto range_of = [&](u32 p2) { return (u32)((u64)p2 * R / ((u64)max_p2 + 1)); };
+    std::vector<RecKey> keys(n_rec), order(n_rec);
+    std::vector<u32> cnt((size_t)T * R, 0), start((size_t)T * R + 1, 0);
     std::vector<s32> sims(n_rec);
-    std::atomic<u32> arrived{0}; std::atomic<u32> phase_no{0};
-    auto barrier = [&]() {                                      // all T threads
-        const u32 ph = phase_no.load(std::memory_order_acquire);
-        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == T) { arrived.store(0, std::memory_order_relaxed); phase_no.store(ph + 1, std::memory_order_release); }
-        else while (phase_no.load(std::memory_order_acquire) == ph) std::this_thread::yield();
-    };
-    auto work = [&](u32 t) {
-        std::sort(order.begin() + part(t), order.begin() + part(t + 1), less);
-        for (u32 w = 1; w < T; w <<= 1) {                       // runs of w chunks -> runs of 2w chunks
-            if (T > 1) barrier();
-            if (t % (2 * w) == 0 && t + w < T)
-                std::inplace_merge(order.begin() + part(t), order.begin() + part(t + w), order.begin() + part(std::min(t + 2 * w, T)), less);
-        }
-        if (T > 1) barrier();
-        for (u32 k = part(t); k < part(t + 1); k++) {
-            const LzHspRec& r = recs[order[k].idx];
-            s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
-            u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
-            s32 sim = r.score;
-            if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
-                const u32* mc = match_counts ? match_counts + 5 * (size_t)order[k].idx : nullptr;
-                double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
-                              : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
-                sim = (s32)(sim * q);                           // "similarity *= q" on an s32 score
+    std::vector<u32> kept((size_t)T + 1, 0);
+    std::atomic<int> bad{0};
+    const std::function<void(size_t, size_t)> make_keys = [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++)
+            for (u32 i = part((u32)t); i < part((u32)t + 1); i++) {
+                u32 pt = 0, pq = 0, probe = 0;
+                if (match_counts) probe = match_counts[5 * (size_t)i + 4];
+                else {
+                    if (!host_window_word(thost, recs[i].seed_pos1, sd, ctb, pt) ||
+                        !host_window_word(qhost, recs[i].seed_pos2, sd, ctb, pq)) { bad.store(1); probe = 0; }
+                    else { const u32 x = pt ^ pq; for (probe = 0; probe < (u32)sd.nprobes; probe++) if (sd.probe_xor[probe] == x) break; }
+                }
+                if (probe >= (u32)sd.nprobes) { bad.store(1); probe = 0; }
+                keys[i] = { ((u64)recs[i].seed_pos2 << 32) | probe, ~recs[i].seed_pos1, i };
+                cnt[t * R + range_of(recs[i].seed_pos2)]++;
             }
-            sims[k] = sim;
+    };
+    const std::function<void(size_t, size_t)> deal = [&](size_t lo, size_t hi) {      // part t's keys to their ranges
+        for (size_t t = lo; t < hi; t++) {
+            std::vector<u32> at(R);
+            for (u32 r = 0; r < R; r++) at[r] = start[(size_t)r * T + t];
+            for (u32 i = part((u32)t); i < part((u32)t + 1); i++) order[at[range_of((u32)(keys[i].hi >> 32))]++] = keys[i];
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (u32 t = 1; t < T; t++) th.emplace_back(work, t);
-        work(0u);
-        for (auto& x : th) x.join();
-    }
-    out.reserve(n_rec);
-    for (u32 k = 0; k < n_rec; k++) {
-        if (sims[k] < K) continue;
-        const LzHspRec& r = recs[order[k].idx];
-        const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
-        out.push_back({ r.end1, (u32)((s32)r.end1 - diag), r.length, sims[k] });
-        if (order_out) { order_out->push_back(order[k].hi); order_out->push_back((u64)order[k].lo); }
-    }
+    const std::function<void(size_t, size_t)> sort_range = [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; r++) std::sort(order.begin() + start[r * T], order.begin() + start[(r + 1) * T], less);
+    };
+    const std::function<void(size_t, size_t)> entropy = [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            u32 n_kept = 0;
+            for (u32 k = part((u32)t); k < part((u32)t + 1); k++) {
+                const LzHspRec& r = recs[order[k].idx];
+                s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+                u32 pos1 = r.end1, pos2 = (u32)((s32)pos1 - diag), length = r.length;
+                s32 sim = r.score;
+                if (entropic && sim >= zero_thresh && (s64)sim <= 3 * (s64)K) {
+                    const u32* mc = match_counts ? match_counts + 5 * (size_t)order[k].idx : nullptr;
+                    double q = mc ? lzh_entropy_from_counts((int)mc[0], (int)mc[1], (int)mc[2], (int)mc[3], (int)length)
+                                  : lzh_hsp_entropy(thost + pos1 - length, qhost + pos2 - length, (int)length);
+                    sim = (s32)(sim * q);                       // "similarity *= q" on an s32 score
+                }
+                sims[k] = sim;
+                if (sim >= K) n_kept++;
+            }
+            kept[t + 1] = n_kept;
+        }
+    };
+    const std::function<void(size_t, size_t)> write_out = [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            u32 w = kept[t];
+            for (u32 k = part((u32)t); k < part((u32)t + 1); k++) {
+                if (sims[k] < K) continue;
+                const LzHspRec& r = recs[order[k].idx];
+                const s32 diag = (s32)r.seed_pos1 - (s32)r.seed_pos2;
+                out[w] = { r.end1, (u32)((s32)r.end1 - diag), r.length, sims[k] };
+                if (order_out) { (*order_out)[2 * (size_t)w] = order[k].hi; (*order_out)[2 * (size_t)w + 1] = (u64)order[k].lo; }
+                w++;
+            }
+        }
+    };
+    if (T > 1) pool.begin_burst();
+    pool.run(T, 1, make_keys);
+    if (bad.load()) { if (T > 1) pool.end_burst(); return LZGPU_ERR_STATE; }
+    { u32 acc = 0; for (u32 r = 0; r < R; r++) for (u32 t = 0; t < T; t++) { start[(size_t)r * T + t] = acc; acc += cnt[(size_t)t * R + r]; } start[(size_t)R * T] = acc; }
+    pool.run(T, 1, deal);
+    pool.run(R, 1, sort_range);
+    pool.run(T, 1, entropy);
+    for (u32 t = 0; t < T; t++) kept[t + 1] += kept[t];
+    out.resize(kept[T]);
+    if (order_out) order_out->resize(2 * (size_t)kept[T]);
+    pool.run(T, 1, write_out);
+    if (T > 1) { pool.end_burst(); pool_lock.unlock(); }
     return 0;
 }

@@ -3,6 +3,13 @@
 // tests/emul can link them and check them on a machine without a GPU.
 #pragma once
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <atomic>
+#include <functional>
+#include <system_error>
+#include <vector>
 #include "lz_common.hpp"
 #include "../../include/lzgpu.h"
 
@@ -84,3 +91,48 @@ void lzh_sort4(It first, It last, Less less)
     std::inplace_merge(q[0], q[2], q[4], less);
 }
 
+// A few helper threads for the host loops of one big problem (a 50 Mbp strand: 79 k anchors, 1150 alignments built per
+// round).  They sleep on a condition variable between the rounds and spin during a commit pass (begin_burst /
+// end_burst): a fork-join then costs a few microseconds, so that loops of a few hundred items are worth handing out
+// (starting a std::thread per loop cost 30-50 us each: round 3's attempts at this lost what they won).
+class ForkJoin {
+    std::vector<std::thread> th;
+    std::mutex m; std::condition_variable cv;
+    std::atomic<bool> burst{false}, quit{false};
+    std::atomic<unsigned long long> gen{0};
+    std::atomic<size_t> next{0}; std::atomic<int> busy{0};
+    size_t n = 0, chunk = 1; const std::function<void(size_t, size_t)>* fn = nullptr;
+    void drain() { for (;;) { const size_t a = next.fetch_add(chunk); if (a >= n) break; (*fn)(a, a + chunk < n ? a + chunk : n); } }
+    void worker()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            if (!burst.load(std::memory_order_acquire)) {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return burst.load() || quit.load(); });
+            }
+            if (quit.load()) return;
+            const unsigned long long g = gen.load(std::memory_order_acquire);
+            if (g == seen) { std::this_thread::yield(); continue; }
+            seen = g;
+            drain();
+            busy.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+public:
+    explicit ForkJoin(unsigned workers) { try { for (unsigned k = 0; k < workers; k++) th.emplace_back([this] { worker(); }); } catch (const std::system_error&) {} }
+    ~ForkJoin() { { std::lock_guard<std::mutex> lk(m); quit.store(true); } cv.notify_all(); for (auto& t : th) t.join(); }
+    unsigned threads() const { return (unsigned)th.size(); }
+    void begin_burst() { if (th.empty()) return; { std::lock_guard<std::mutex> lk(m); burst.store(true, std::memory_order_release); } cv.notify_all(); }
+    void end_burst() { burst.store(false, std::memory_order_release); }
+    // f(lo, hi) over [0, count) in chunks, on the helpers and the caller; returns when every chunk is done
+    void run(size_t count, size_t chunk_, const std::function<void(size_t, size_t)>& f)
+    {
+        if (th.empty() || !burst.load() || count <= chunk_) { f(0, count); return; }
+        n = count; chunk = chunk_; fn = &f; next.store(0);
+        busy.store((int)th.size());
+        gen.fetch_add(1, std::memory_order_acq_rel);
+        drain();
+        while (busy.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+};
