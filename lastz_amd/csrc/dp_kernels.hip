@@ -303,7 +303,8 @@ struct HipDpExec : LzDpExecutor {
             if (const char* e = getenv("LZGPU_DP_REPL")) repl = !bounds && e[0] == '1';      // tests / A-B: force one or the other
             auto kern = P.no_trim ? (bounds ? k_ydrop<true, true, false> : repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>)
                                   : (bounds ? k_ydrop<false, true, false> : repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32), c.dp_stream,
+            static const size_t pad_lds = []() { const char* e = getenv("LZGPU_DP_PAD_LDS"); return (size_t)(e ? atol(e) : 0); }();   // occupancy experiments: fewer DPs per CU
+            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32) + pad_lds, c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
         }
         c.dp_timer.end(c.dp_stream);
@@ -321,7 +322,8 @@ struct HipDpExec : LzDpExecutor {
             }
         if (const char* dump = getenv("LZGPU_DPDUMP")) {            // profiling aid: one line per DP of the launch
             if (FILE* f = fopen(dump, "a")) {
-                for (u32 id : ids) fprintf(f, "%u %u %llu %u %u\n", jobs[id].est_rows, all[id].max_row, (unsigned long long)all[id].cells, all[id].status, slot);
+                for (u32 id : ids) fprintf(f, "%u %u %llu %u %u %llu %llu %llu\n", jobs[id].est_rows, all[id].max_row, (unsigned long long)all[id].cells, all[id].status, slot,
+                                           (unsigned long long)all[id].t_rows, (unsigned long long)all[id].t_begin, (unsigned long long)all[id].t_end);
                 fclose(f);
             }
         }
