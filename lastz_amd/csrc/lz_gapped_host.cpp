@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <unordered_map>
+#include <deque>
 #include "lz_gapped_host.hpp"
 #include "lz_host.hpp"
 
@@ -499,7 +500,21 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     // A finished speculative DP pair stays usable across windows for as long as its validity
     // conditions hold against the alignments committed after the snapshot it ran against.
     struct Cached { u32 a1, a2; Neighbours nb; size_t n_snap; LzDpResult rl, rr; std::vector<u32> ol, orr; };
-    std::unordered_map<u32, Cached> cache;
+    // (indexed by anchor: the window scan looks every anchor up -- 3 x 10^5 per strand of the 200 Mbp pair, nearly all of them
+    // misses -- and a hash table made that look-up the scan's whole cost: 15 of its 16 ms)
+    struct AnchorCache {
+        std::vector<s32> ix; std::deque<Cached> pool; std::vector<s32> free_list;
+        explicit AnchorCache(size_t n) : ix(n, -1) {}
+        Cached* find(u32 j) { return ix[j] >= 0 ? &pool[(size_t)ix[j]] : nullptr; }
+        void erase(u32 j) { if (ix[j] >= 0) { pool[(size_t)ix[j]] = Cached(); free_list.push_back(ix[j]); ix[j] = -1; } }
+        Cached& emplace(u32 j, Cached&& c)
+        {
+            s32 k;
+            if (!free_list.empty()) { k = free_list.back(); free_list.pop_back(); pool[(size_t)k] = std::move(c); }
+            else { k = (s32)pool.size(); pool.push_back(std::move(c)); }
+            ix[j] = k; return pool[(size_t)k];
+        }
+    } cache(n_anchors);
     struct Prebuilt { Built b; std::vector<LzDpSeg> segs; bool have = false; };
     std::vector<Prebuilt> prebuilt;                            // per SPECULATED entry of the window: what its commit would build
     std::vector<u32> spec_of, spec_list;                       // entry -> its place in prebuilt / the speculated entries
@@ -540,11 +555,11 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (ok < 0) return LZGPU_ERR_STATE;
             if (ok == 0) { cache.erase(j); continue; }         // on an earlier alignment: gone for good
             const s64 dg = (s64)a1 - (s64)a2;
-            auto hit = cache.find(j);
+            Cached* const hit = cache.find(j);
             // (the selected anchors are kept in cells of NEAR_DIAG diagonals: a near one is in the anchor's
             // cell or one next to it -- a window scans up to 64 K anchors against up to 1 K selected ones)
             const s64 cell = (dg >= 0 ? dg : dg - (NEAR_DIAG - 1)) / NEAR_DIAG;
-            if (hit == cache.end()) {
+            if (hit == nullptr) {
                 // 0 = not near, 1 = near (loose), 2 = near and almost on the same diagonal (tight)
                 int near = 0; u32 near_slot = 0;
                 for (s64 cc = cell - 1; cc <= cell + 1 && near < 2; cc++) {
@@ -571,7 +586,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (slot_members.size() < ext_l.size()) slot_members.emplace_back();
             if (prof) slot_anchor.push_back({ dg, (s64)a1 });
             entries.push_back({ j, true, (u32)ext_l.size() - 1 });
-            if (hit != cache.end()) continue;                  // result of an earlier round, re-validated at commit
+            if (hit != nullptr) continue;                      // result of an earlier round, re-validated at commit
             // get_above_below, :4043-4059
             s32 below, above;
             above_below(S, a1, below, above);
@@ -603,7 +618,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             int rc = exec.run(S, jobs, res, ops);
             if (rc) return rc;
             for (size_t k = 0; k < fresh.size(); k++) {
-                Cached& cr = cache[fresh[k]];
+                Cached& cr = *cache.find(fresh[k]);
                 cr.rl = res[2 * k]; cr.rr = res[2 * k + 1];
                 cr.ol.swap(ops[2 * k]); cr.orr.swap(ops[2 * k + 1]);
             }
@@ -620,9 +635,9 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         {
             const std::function<void(size_t, size_t)> build = [&](size_t lo, size_t hi) {
                 for (size_t k = lo; k < hi; k++) {
-                    auto it = cache.find(entries[spec_list[k]].anchor_ix);   // (concurrent look-ups only: nothing is inserted or erased here)
-                    if (it == cache.end()) continue;
-                    const Cached& sp = it->second;
+                    const Cached* it = cache.find(entries[spec_list[k]].anchor_ix);   // (concurrent look-ups only: nothing is inserted or erased here)
+                    if (it == nullptr) continue;
+                    const Cached& sp = *it;
                     Prebuilt& pb = prebuilt[k];
                     splice_and_trim(G, sp.a1, sp.a2, sp.rl, sp.ol, sp.rr, sp.orr, pb.b);
                     format_segments(pb.b, pb.segs);
@@ -664,8 +679,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                             (long long)((s64)anchors[aix].pos1 - slot_anchor[entries[e].near_slot].second));
                 next = aix; cut = true; break;
             }
-            auto it = cache.find(aix);
-            const Cached& sp = it->second;
+            const Cached& sp = *cache.find(aix);
             const LzDpResult& rl = sp.rl; const LzDpResult& rr = sp.rr;
             // Is the cached DP the one the reference would run now?  Rectangles the two one-sided
             // DPs explored, +-2 cells (target rows x query columns):
@@ -690,7 +704,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (prof) t_c_chk += now() - tq1;
             const double tq2 = prof ? now() : 0;
             struct Lap { double& acc; double t0; bool on; std::function<double()> clk; ~Lap() { if (on) acc += clk() - t0; } } lap_build{ t_c_build, tq2, prof, now };
-            if (!same) { cache.erase(it); next = aix; cut = true; st.reruns++; break; }
+            if (!same) { cache.erase(aix); next = aix; cut = true; st.reruns++; break; }
             st.anchors_extended++;
             st.dp_cells += rl.cells + rr.cells;
             st.truncated += (rl.truncated ? 1 : 0) + (rr.truncated ? 1 : 0);     // :3640-3661: the reference warns on stderr
@@ -698,7 +712,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (!pb.have) { splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, pb.b); format_segments(pb.b, pb.segs); }
             Built& b = pb.b;
             std::vector<LzDpSeg>& segs = pb.segs;
-            cache.erase(it);
+            cache.erase(aix);
             if (segs.empty()) continue;                        // empty alignment, :1401-1405
             if (!G.all_bounds && b.s < G.score_thresh) continue;     // :1419-1429
             LzDpAlign m; memset(&m, 0, sizeof(m));
