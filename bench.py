@@ -10,15 +10,23 @@ the reference's order.  After the timed steps the same process adds, outside `va
   parity    SHA-256 of the HSP list and of the LAV the lastz CLI bound to this library writes for this exact pair,
             against the fingerprints of the pristine reference's output (tests/golden/bench50m.sha.json, made by
             tests/golden/make_bench_sha.py: 2 x 40 minutes of CPU) -- and the CLI's wall clock
+  chain     N2: lzgpu_reduce_to_chain (a host routine) on the pair's HSPs, strand by strand: its clock
+  cli       the bound lastz on the pair, four runs back to back: first after this process freed its device memory, median, minimum
+  north_star  the same legs on BASELINE.json's north-star pair (200 Mbp x 200 Mbp): seed stage (1 warm-up + 2 timed steps), gapped
+            batch, chain clock, one CLI run, parity against tests/golden/bench200m.sha.json (--no-north-star skips it)
+  content   the seed stage on the same pair with 40 % soft-masked bases + N runs, and with sparse IUPAC codes (scan mode 1)
   cpu_baseline  the pristine reference binary on the box's host cores: 1 core (lastz is single-threaded) and the whole
             host (one process per core over query units, the reference's own scale-out model), on a bounded sample
 
 N > 1 (one process per GPU, torch.distributed / RCCL): workload = BASELINE.json configs[3] in its shape: 200 Mbp target
 against 15 query sequences x 2 strands = 30 units, LPT-sharded over the ranks (strong scaling: the job is fixed), the
-position table built on rank 0 and broadcast over RCCL/xGMI once per job, HSP lists gathered and merged on rank 0 in
-the reference's order.  A step = the whole job.  (--q-unit-len / --q-units / --tlen scale it for smoke runs.)
+position table built on rank 0 and broadcast over RCCL/xGMI once per job; every rank searches its units AND runs their gapped
+stage (--ydrop=9430), unit k's on a second host thread and stream beside unit k + 1's search; HSP lists and alignment digests
+gathered and merged on rank 0 in the reference's order.  A step = the whole job.  (--q-unit-len / --q-units / --tlen-multi scale
+it for smoke runs; --bucket-owners splits every unit's search over the ranks by hashed-diagonal ownership; --force-multi runs
+this code path on one rank.)
 
-One JSON line on rank 0 (driver contract); extra objects: roofline, cpu_baseline, gapped, parity, cli.
+One JSON line on rank 0 (driver contract); extra objects: roofline, cpu_baseline, gapped, chain, parity, cli, north_star, content.
 """
 import argparse
 import hashlib
