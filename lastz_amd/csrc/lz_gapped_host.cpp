@@ -117,6 +117,19 @@ static bool on_alignment(const LzHostSnapshot& S, const LzDpAlign& al, u32 pos1,
     return x == 0;
 }
 
+// the same test against the pieces of an alignment that is not in the snapshot yet (what a commit would add)
+static bool on_pieces(const std::vector<LzDpSeg>& segs, u32 pos1, u32 pos2)
+{
+    if (segs.empty() || segs.front().b1 > pos1 || segs.back().e1 < pos1) return false;
+    size_t slo = 0, shi = segs.size();
+    while (slo < shi) { const size_t m = slo + (shi - slo) / 2; if (segs[m].e1 >= pos1) shi = m; else slo = m + 1; }
+    if (slo >= segs.size()) return false;
+    const LzDpSeg& g = segs[slo];
+    if (g.type == LZ_HORZ_SEG) return false;
+    const s32 x = (g.type == LZ_DIAG_SEG) ? LZ_SDIFF(g.b2, pos2) + LZ_SDIFF(pos1, g.b1) : LZ_SDIFF(g.b2, pos2);
+    return x == 0;
+}
+
 // the reference's walk (src/gapped_extend.c:3953-4028), kept as the yardstick of lzh_selftest_neighbours
 static int msp_left_right_plain(const LzHostSnapshot& S, u32 pos1, u32 pos2, Neighbours& nb)
 {
@@ -632,6 +645,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         spec_list.clear();
         for (size_t e = 0; e < entries.size(); e++) if (entries[e].speculated) { spec_of[e] = (u32)spec_list.size(); spec_list.push_back((u32)e); }
         prebuilt.clear(); prebuilt.resize(spec_list.size());
+        covered.assign(entries.size(), 0);
         {
             const std::function<void(size_t, size_t)> build = [&](size_t lo, size_t hi) {
                 for (size_t k = lo; k < hi; k++) {
@@ -642,6 +656,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                     splice_and_trim(G, sp.a1, sp.a2, sp.rl, sp.ol, sp.rr, sp.orr, pb.b);
                     format_segments(pb.b, pb.segs);
                     pb.have = true;
+                    // ... and which of the deferred anchors found near this one lie on that alignment (a slot's members belong
+                    // to this entry alone: no two threads write the same flag); it counts once the alignment is committed
+                    const u32 slot = entries[spec_list[k]].near_slot;
+                    if (slot < slot_members.size()) for (const Member& mb : slot_members[slot]) if (on_pieces(pb.segs, mb.pos1, mb.pos2)) covered[mb.e] = 1;
                 }
             };
             helpers.begin_burst();
@@ -653,7 +671,6 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         // ---- commit in the reference's order
         bool cut = false;
         std::vector<s32> slot_align(ext_l.size(), -1);        // alignment committed for a selected anchor of this window
-        covered.assign(entries.size(), 0);
         for (size_t e = 0; e < entries.size(); e++) {
             const u32 aix = entries[e].anchor_ix;
             Neighbours nb;
@@ -661,7 +678,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             // alignment" needs no more than one witness (:3953-4028): that was tested for all of a slot's deferred
             // anchors at once when the slot's alignment was committed (below); one flag to read here.  (A deferred
             // anchor has no cached DP: nothing to erase.)
-            if (covered[e]) continue;
+            if (covered[e] && !entries[e].speculated && entries[e].near_slot < slot_align.size() && slot_align[entries[e].near_slot] >= 0) continue;
             const double tq0 = prof ? now() : 0;
             int ok = msp_left_right(S, anchors[aix].pos1, anchors[aix].pos2, nb);
             if (prof) t_c_lr += now() - tq0;
@@ -709,7 +726,10 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             st.dp_cells += rl.cells + rr.cells;
             st.truncated += (rl.truncated ? 1 : 0) + (rr.truncated ? 1 : 0);     // :3640-3661: the reference warns on stderr
             Prebuilt& pb = prebuilt[spec_of[e]];
-            if (!pb.have) { splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, pb.b); format_segments(pb.b, pb.segs); }
+            if (!pb.have) {
+                splice_and_trim(G, sp.a1, sp.a2, rl, sp.ol, rr, sp.orr, pb.b); format_segments(pb.b, pb.segs);
+                if (entries[e].near_slot < slot_members.size()) for (const Member& mb : slot_members[entries[e].near_slot]) if (on_pieces(pb.segs, mb.pos1, mb.pos2)) covered[mb.e] = 1;
+            }
             Built& b = pb.b;
             std::vector<LzDpSeg>& segs = pb.segs;
             cache.erase(aix);
@@ -733,22 +753,6 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
             if (entries[e].near_slot < slot_align.size()) {
                 const u32 slot = entries[e].near_slot;
                 slot_align[slot] = (s32)S.aligns.size() - 1;
-                // the slot's deferred anchors that come later in the order: on this alignment?  One binary search each over
-                // the pieces of ONE alignment (hot in the cache), on a few threads when the alignment swallows thousands
-                const std::vector<Member>& mem = slot_members[slot];
-                const LzDpAlign& al = S.aligns.back();
-                auto check = [&](size_t lo, size_t hi) {
-                    for (size_t k = lo; k < hi; k++) {
-                        if (mem[k].e > e && on_alignment(S, al, mem[k].pos1, mem[k].pos2)) covered[mem[k].e] = 1;
-                    }
-                };
-                if (mem.size() < (helper_min ? 8192u : 8u)) check(0, mem.size());
-                else {                                          // (an alignment that swallows thousands of anchors: worth waking the helpers)
-                    const std::function<void(size_t, size_t)> chk = check;
-                    helpers.begin_burst();
-                    helpers.run(mem.size(), helper_min ? 1024 : 1, chk);
-                    helpers.end_burst();
-                }
             }
             if (G.max_paired_bases) {                          // count_paired_bases, :5695-5706; the limit test of :1441-1459
                 for (const LzDpSeg& g : segs) if (g.type == LZ_DIAG_SEG) paired_bases += (u64)g.e1 + 1 - g.b1;
