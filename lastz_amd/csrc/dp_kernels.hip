@@ -101,8 +101,9 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
     __device__ __forceinline__ s32 scan_gap_plain(LzDpSharedBase& sh, s32 x0, s32 gap_e, u32 cpl, u32 width)
     {
         const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        const u32 ci = ((u32)lane + 1u) * cpl, ce = (u32)lane * cpl;
-        const s32 cum_incl = gap_e * (s32)(ci < width ? ci : width), cum_excl = gap_e * (s32)(ce < width ? ce : width);
+        // (24-bit multiplies: lanes, cells per lane, widths and the gap-extension penalty are all far below 2^23)
+        const u32 ce = __umul24((u32)lane, cpl), ci = ce + cpl;
+        const s32 cum_incl = __mul24(gap_e, (s32)(ci < width ? ci : width)), cum_excl = __mul24(gap_e, (s32)(ce < width ? ce : width));
         const s32 x = regs.A + cum_incl;
         s32 inc = x;
         LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
@@ -113,7 +114,7 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 #pragma unroll
         for (int j = 0; j < LZ_DP_WAVES; j++) { const s32 v = sh.wc[j]; if (j < w && v > pre) pre = v; if (v > all) all = v; }
         regs.i_in = (ex > pre ? ex : pre) - cum_excl;
-        return all - gap_e * (s32)width;
+        return all - __mul24(gap_e, (s32)width);
     }
     __device__ __forceinline__ void scan_cand(LzDpSharedBase& sh, s32 b0)
     {

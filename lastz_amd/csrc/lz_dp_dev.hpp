@@ -243,6 +243,13 @@ LZ_HD u32 lz_dp_b(const LzDpParams& P, const LzDpJob& J, u32 col)
 #define LZ_PHASE_CLOCK() ((u64)0)
 #endif
 #define LZ_SDIFF(a, b) (((s32)(a)) - ((s32)(b)))
+// lane x cells-per-lane and the like: 24-bit operands, one full-rate instruction (a 32 x 32-bit v_mul_lo_u32 runs at a quarter of
+// the rate, and the batch launches of k_ydrop are bound by vector-instruction issue)
+#if defined(__HIP_DEVICE_COMPILE__)
+LZ_HD u32 lz_mul24(u32 a, u32 b) { return __umul24(a, b); }
+#else
+LZ_HD u32 lz_mul24(u32 a, u32 b) { return a * b; }
+#endif
 #define LZ_RING(c) ((c) & (SH::RING - 1))
 
 // next_sweep_seg / prev_sweep_seg, src/gapped_extend.c:4754-4850
@@ -626,7 +633,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         // walk 1: block summaries of the insertion recurrence
         const u64 ta = LZ_PHASE_CLOCK();
         x.step([&](int lane, LzDpLane& r) {
-            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            u32 c0 = LY0 + lz_mul24((u32)lane, cpl), c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
             const s32 cl = sh.cc[LZ_RING(c0 - 1u)];             // (unconditional: issued with the batch's reads; selected below)
             load_batch(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
@@ -664,7 +671,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         const u64 tb_ = LZ_PHASE_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.step([&](int lane, LzDpLane& r) {
-            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            u32 c0 = LY0 + lz_mul24((u32)lane, cpl), c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
             // one batch: the new C, D and links replace the old values in vcc / vdd / vlk
@@ -714,7 +721,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         // walk 3: prune test against the running best, final stores, traceback bytes
         const u32 a_nx = sh.aa[row & (LZ_DP_LANES - 1)];        // (next row's A class: not used when that row opens a new block)
         x.step([&](int lane, LzDpLane& r) {
-            u32 c0 = LY0 + (u32)lane * cpl, c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
+            u32 c0 = LY0 + lz_mul24((u32)lane, cpl), c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 rb = r.run_in;
             u32 first = 0xFFFFFFFFu, last = 0xFFFFFFFFu;
             u8* tbr = tb + (u32)(trow_cur + c0);
