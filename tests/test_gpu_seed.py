@@ -378,6 +378,26 @@ def test_full_size_properties(gpu):
             assert raw == h["score"]
 
 
+def test_north_star_pair_against_the_reference_fingerprints(gpu):
+    """BASELINE.json north_star size (200 Mbp x 200 Mbp, both strands): the HSP list of the seed stage and the alignments of the gapped
+    stage against the pristine reference's output for this exact pair (tests/golden/bench200m.sha.json: four one-strand reference
+    processes of ~5.4 h each, tests/golden/make_bench200m_sha.py).  The LAV's own SHA is checked by bench.py through the bound CLI."""
+    import json, bench
+    from lastz_amd import lzgpu
+    gold = json.load(open(os.path.join(H.GOLDEN, "bench200m.sha.json")))
+    t, q = seqio.synth_pair(gold["tlen"], gold["qlen"], seed=gold["seed"])
+    sub, masked = H.scoring()
+    gpu.table_prepare(t, gpu.seed(H.DEFAULT_SEED, 1), CTB)
+    gpu.set_hit_capacity(1 << 31)
+    gpu.query_upload(0, q); gpu.query_upload(1, seqio.revcomp(q))
+    hs = [gpu.seed_hit_search(masked, slot=s) for s in (0, 1)]
+    gpu.set_hit_capacity(1 << 28)
+    sha, rows = bench.hsp_rows_sha(hs)
+    assert rows == gold["hsp_rows"] and sha == gold["hsp_sha"]
+    res = gpu.gapped_extend_batch(sub, [dict(anchors=bench.hsps_to_segs(lzgpu, h, s), slot=s, ydrop=9430) for s, h in enumerate(hs)])
+    assert sum(len(al) for al, _ in res) == gold["lav_blocks"]
+
+
 @pytest.mark.skipif(lzo.ref_binary() is None, reason="oracle/_ref/lastz not present")
 def test_live_against_reference_binary(gpu, tmp_path):
     """same run, same inputs: the pristine reference binary vs the HIP path"""
