@@ -17,8 +17,10 @@
  * supported, with ONE exception (round 4): B3 has its own stream, timer and buffers, so one thread may be inside
  * lzgpu_gapped_extend / lzgpu_gapped_extend_batch on resident query slots while another is inside
  * lzgpu_seed_hit_search / lzgpu_query_upload on OTHER slots -- the gapped stage of unit k beside the search of unit
- * k+1 (bench.py --gpus N; src/lastz.c:3401-3419 runs them one after the other).  Two B2 calls or two B3 calls at once
- * remain unsupported.  The library itself uses a few worker threads for host-side loops and joins them before returning.
+ * k+1 (bench.py --gpus N; src/lastz.c:3401-3419 runs them one after the other).  The exception covers RESIDENT slots only:
+ * a query handed in as a host pointer is uploaded to a transient slot by the call itself, and two concurrent calls must not
+ * both do that for the same sequence's sake -- upload it once (lzgpu_query_upload) and name the slot.  lzgpu_last_error() is
+ * per calling thread.  Two B2 calls or two B3 calls at once remain unsupported.  The library itself uses a few worker threads for host-side loops and joins them before returning.
  *
  * Return codes, every int-returning entry point:
  *     0   done, results are complete and bit-identical to the reference's

@@ -108,11 +108,14 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
         s32 inc = x;
         LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
         const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
-        if (wl == 63) sh.wc[w] = inc;                           // (wc[] is free here: scan_cand rewrites it behind the next barrier)
+        // (partials in wg[].A, which the plain scan has to itself -- scan_gap is the other kernel's -- and which is not written again
+        // before the next row's barriers.  NOT wc[]: walk 2 has no barrier, so a fast wave's scan_cand could store its wc[w] before a
+        // slower wave of the workgroup has read this scan's partials from it: ADVICE r4)
+        if (wl == 63) sh.wg[w].A = inc;
         __syncthreads();
         s32 pre = x0, all = x0;
 #pragma unroll
-        for (int j = 0; j < LZ_DP_WAVES; j++) { const s32 v = sh.wc[j]; if (j < w && v > pre) pre = v; if (v > all) all = v; }
+        for (int j = 0; j < LZ_DP_WAVES; j++) { const s32 v = sh.wg[j].A; if (j < w && v > pre) pre = v; if (v > all) all = v; }
         regs.i_in = (ex > pre ? ex : pre) - cum_excl;
         return all - __mul24(gap_e, (s32)width);
     }
@@ -628,7 +631,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     std::vector<GappedProblem> gp(n);
     std::map<SeqSlot*, bool> encoded;                          // (problems may share a query slot -- the windows of a strand: encoded once)
     for (u32 k = 0; k < n; k++)
-        if ((rc = gapped_prepare(c, &args[k], -1 - (int)k, rowc, colc, k == 0, encoded, gp[k]))) return rc;
+        if ((rc = gapped_prepare(c, &args[k], LZ_TEMP_SLOT_B3 - (int)k, rowc, colc, k == 0, encoded, gp[k]))) return rc;    // (B2's transient slot is -1: the two ranges are disjoint)
     if ((rc = g_dp.tab.ensure(sizeof(tab)))) return rc;
     LZ_HIP(hipMemcpyAsync(g_dp.tab.p, tab, sizeof(tab), hipMemcpyHostToDevice, c.dp_stream));
     LZ_HIP(hipStreamSynchronize(c.dp_stream));
@@ -683,6 +686,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     }
     const double hp_worked = hp_ms();
     for (u32 k = 0; k < n; k++) {
+        std::lock_guard<std::mutex> lk(c.counters_m);
         c.counters.anchors_extended += st[k].anchors_extended; c.counters.dp_cells += st[k].dp_cells;
         c.counters.gapped_extensions += st[k].dp_runs; c.counters.truncated_extensions += st[k].truncated;
     }

@@ -115,7 +115,10 @@ struct Chain {
                 if (p > bp.contrib) { bp.contrib = p; bp.num = j; }
             }
         } else if (axis == 1) {
-            const int ax = (int)lower;                           // (sic: the children's "axis")
+            // (sic: the children's "axis".  The reference's default build converts with x86's cvttsd2si, which yields INT_MIN for
+            // every double outside int's range -- a conversion that is undefined in C++; spelled out here so that another compiler
+            // or target picks the same child: ADVICE r4)
+            const int ax = (lower >= -2147483648.0 && lower < 2147483648.0) ? (int)lower : (int)0x80000000;
             const bigscore lb = (bigscore)(int)(1u - (unsigned)axis);   // (sic: their lower bound)
             if ((s32)y >= nd.cut) search(nd.hi_son, ax, lb, bp);
             search(nd.lo_son, ax, lb, bp);

@@ -72,7 +72,9 @@ struct LzCtx {
     u64 num_words = 0;
 
     // ---- queries
-    std::map<int, SeqSlot> queries; // slot -> resident query; slot -1 = transient (map nodes are stable: a slot's address survives other slots' insertion)
+    std::map<int, SeqSlot> queries; // slot -> resident query; slot -1 = B2's transient slot (a host-pointer query), LZ_TEMP_SLOT_B3 - k = problem k of a B3 batch
+                                    // that came with a host pointer (map nodes are stable: a slot's address survives other slots' insertion)
+#define LZ_TEMP_SLOT_B3 (-1000)
     std::mutex slots_m;             // guards look-ups / insertions in `queries` (B2 and B3 may run on two host threads)
 
     // ---- seed-search scratch
@@ -101,7 +103,8 @@ struct LzCtx {
     u64 hit_capacity = (1ull << 31);    // hits per chunk (LZGPU_HIT_CAPACITY): 2^28 -> 2^30 took 10 ms off the 50 Mbp step (fewer launches, fewer passes over the sorted words), 2^30 -> 2^31 another 5.5 (a 50 Mbp strand is one chunk); the buffers follow the largest chunk: 21 bytes per hit, 42 GiB at most
     u64 hsp_capacity = (1ull << 24);
 
-    lz_counters counters = {};
+    lz_counters counters = {};      // B2 and B3 write disjoint fields (possibly from two host threads); lzgpu_counters copies under counters_m
+    std::mutex counters_m;
     KernelTimer timer;              // B1 / B2 launches (the caller's thread)
     KernelTimer dp_timer;           // B3 launches (dp_stream; possibly another host thread)
 };

@@ -155,7 +155,6 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
     // a lane leaves the straight-line part at its first failing group (divergent exit: the lane is masked off in
     // EXEC, nothing has to be frozen with selects: 7 instead of 11 VALU instructions per group; measured
     // k_scan_hits 81 -> 77 ms per step against the select form below, which the host build keeps)
-#if !defined(LZ_LUT_PRELOAD)
     {
         // the entries of even / odd groups in two variables that take turns: the one the walk stopped on is still
         // there after the exit (no per-group copy of it)
@@ -178,30 +177,6 @@ LZ_HD void lz_lut_window(const LzLutParams& P, const LzLutEntry* lut, s32 diag, 
         fsc = (np & 1u) ? eb.sc : ea.sc;
 #undef LZ_LUT_ENTRY_OF
     }
-#else
-    {
-        // -DLZ_LUT_PRELOAD (measured, not the default): all 15 look-ups of the window issued before the walk starts.
-        // 113 VGPRs instead of 89 and no faster (72.0 against 71.8 ms per step): the kernel waits for its window
-        // fetches (the L1 miss queue of a CU is full about half of the time), not for LDS.
-        LzLutEntry e[LZ_LUT_WIN_G];
-        LZ_UNROLL_ALL
-        for (int g = 0; g < LZ_LUT_WIN_G; g++) {
-            const int by = LZ_LUT_GBYTE(RIGHT, g);
-            e[g] = tab[lz_byte_pair(wc[by >> 2], xw[by >> 2], by & 3)];
-        }
-        LZ_UNROLL_ALL
-        for (int g = 0; g < LZ_LUT_WIN_G; g++) { LZ_PIN(e[g].ab); LZ_PIN(e[g].sc); }     // (keeps the compiler from sinking each look-up into the step that uses it)
-        LZ_UNROLL_ALL
-        for (int g = 0; g < LZ_LUT_WIN_G; g++) {
-            fsc = e[g].sc;
-            if (m < (s32)(e[g].ab & 0xFFFFu)) goto groups_done;
-            if (LIMCHK && (u32)g >= glim) goto groups_done;
-            const s32 bq = (s32)e[g].ab >> 16;
-            m = lz_sdot4(e[g].sc, m < bq ? m : bq); run = lz_sdot4(e[g].sc, run); np = (u32)g + 1u;
-        }
-        groups_done: ;
-    }
-#endif
 #else
     {
         bool dead = false;

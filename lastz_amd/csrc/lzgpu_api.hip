@@ -24,12 +24,18 @@ static void lz_release_statics();
 void lz_phase_clocks_print();                                 // seed_kernels.hip (prints only in a -DLZ_PHASE_CLOCKS build)
 LzCtx& lz_ctx() { return g_ctx; }
 
+// The last error message: one per THREAD (B3 may run on a second host thread beside B2, and the problems of a batch run on
+// threads of their own), plus the newest of any thread for a caller that had no failure of its own -- lzgpu_gapped_extend_batch
+// reports a worker's failure from the calling thread.  lzgpu_last_error() hands out the calling thread's own copy: no torn reads,
+// never a pointer into a string another thread may reassign.
+static thread_local std::string t_last_error, t_last_error_out;
+static std::mutex g_err_m;
 int lz_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-    static std::mutex m;                                        // (the problems of lzgpu_gapped_extend_batch run on threads of their own)
-    std::lock_guard<std::mutex> lk(m);
+    t_last_error = buf;
+    std::lock_guard<std::mutex> lk(g_err_m);
     g_ctx.last_error = buf;
     return code;
 }
@@ -125,7 +131,12 @@ int lz_bind_thread()
 }
 static int require_init() { return lz_bind_thread(); }
 
-extern "C" const char* lzgpu_last_error(void) { return g_ctx.last_error.c_str(); }
+extern "C" const char* lzgpu_last_error(void)
+{
+    if (!t_last_error.empty()) t_last_error_out = t_last_error;
+    else { std::lock_guard<std::mutex> lk(g_err_m); t_last_error_out = g_ctx.last_error; }
+    return t_last_error_out.c_str();
+}
 
 extern "C" int lzgpu_probe(void)
 {
@@ -725,8 +736,9 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
                                        c.hsp_mc.as<u32>(), c.stream))) return rc;
     }
     c.timer.resolve();
-    c.counters.words += hc[2]; c.counters.raw_hits += total_hits;
-    c.counters.extensions += hc[0]; c.counters.bp_extended += hc[1];
+    { std::lock_guard<std::mutex> lk(c.counters_m);
+      c.counters.words += hc[2]; c.counters.raw_hits += total_hits;
+      c.counters.extensions += hc[0]; c.counters.bp_extended += hc[1]; }
 
     if (!a->extend) {
         lz_hsp* res = (lz_hsp*)malloc((plain.size() ? plain.size() : 1) * sizeof(lz_hsp));
@@ -752,7 +764,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     lz_hsp* res = (lz_hsp*)malloc((fin.size() ? fin.size() : 1) * sizeof(lz_hsp));
     if (!res) return lz_fail(LZGPU_ERR_OOM, "host malloc failed");
     if (!fin.empty()) memcpy(res, fin.data(), fin.size() * sizeof(lz_hsp));
-    c.counters.hsps += fin.size();
+    { std::lock_guard<std::mutex> lk(c.counters_m); c.counters.hsps += fin.size(); }
     g_hp.lap(6, "host finish (order+entropy)");
     *out = res; *n_out = fin.size();
     return 0;
@@ -814,8 +826,8 @@ extern "C" int lzgpu_window_search(const lz_window_search_args* a, lz_hsp** out,
 
 // ------------------------------------------------------------------------------ instrumentation
 
-extern "C" void lzgpu_counters_reset(void) { memset(&g_ctx.counters, 0, sizeof(g_ctx.counters)); }
-extern "C" int  lzgpu_counters_get(lz_counters* out) { if (!out) return LZGPU_ERR_ARG; *out = g_ctx.counters; return 0; }
+extern "C" void lzgpu_counters_reset(void) { std::lock_guard<std::mutex> lk(g_ctx.counters_m); memset(&g_ctx.counters, 0, sizeof(g_ctx.counters)); }
+extern "C" int  lzgpu_counters_get(lz_counters* out) { if (!out) return LZGPU_ERR_ARG; std::lock_guard<std::mutex> lk(g_ctx.counters_m); *out = g_ctx.counters; return 0; }
 extern "C" void lzgpu_profile_enable(int enable) { g_ctx.timer.enabled = g_ctx.dp_timer.enabled = enable != 0; }
 extern "C" void lzgpu_profile_reset(void) { g_ctx.timer.reset(); g_ctx.dp_timer.reset(); }
 extern "C" int  lzgpu_profile_get(int n, const char** name, uint64_t* launches, double* total_ms)

@@ -843,87 +843,28 @@ __device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzL
     }
     if (valid && !queued) LZ_NT_ST(lz_lut_summary(L, R, P.min_score), summ + idx);
 }
-// The query windows of a hit depend on its query position alone, and the hits of a wave are in discovery order: runs of lanes
-// (39 hits per position on the bench pair: two or three runs per wave) want the same 2 x 16 bytes.  -DLZ_QUERY_SHARE (VERDICT r3
-// 1(b); measured, NOT the default): only the first lane of a run loads them and lz_scan_share hands them to the run through the
-// LDS crossbar (ds_bpermute) when the round that uses them starts.  Results identical; k_scan_hits 66.6 -> 68.0 ms per step on the
-// 50 Mbp pair, 1254 -> 1244 ms at 200 Mbp: sixty-four lanes asking for one line are one request to the L1 already, and the run
-// bookkeeping (a DPP compare, a seven-step prefix maximum, eight crossbar moves per round) costs what the narrower loads save.
-// Returns the run's first lane, times four (the crossbar's address).
-#if defined(LZ_QUERY_SHARE)
-#define LZ_QSHARE 1
-#else
-#define LZ_QSHARE 0
-#endif
+// The windows of a hit: 2 x 16 bytes of the target's 2-bit codes from the half-overlapping blocks (the left window starts at byte bl,
+// the right one at br = bl + 15 or 16, together at most 32 bytes: ONE line of t2x -- block bl / 32, offset bl % 32), 2 x 16 bytes of
+// the query's from the plain array (the hits of a wave are in discovery order: runs of lanes ask for the same query line), and with
+// special bytes about (SP) the same of the two 1-bit masks.  (Variants that were measured and lost -- query windows shared through the
+// LDS crossbar, the plain target array, timing-only what-ifs without the target / with an L2-resident target -- are patches under
+// tools/experiments/, applied by tools/build_variant.sh.)
 template <bool SP>
-__device__ __forceinline__ u32 lz_scan_fetch(const LzLutParams& Q, u64 key, LzLutRaw<SP>& rawl, LzLutRaw<SP>& rawr, u32 lane)
+__device__ __forceinline__ void lz_scan_fetch(const LzLutParams& Q, u64 key, LzLutRaw<SP>& rawl, LzLutRaw<SP>& rawr)
 {
     const u32 pos2 = (u32)key, pos1 = pos2 + (u32)(key >> 32);
     const s32 diag = (s32)(u32)(key >> 32);
-    bool lead = true; u32 src4 = lane << 2;
-    if (LZ_QSHARE) {
-        const u32 prev = lz_dpp_u32<0x138, 0xf, 0xf>(~pos2, pos2);       // wave_shr:1 (lane 0 keeps ~pos2: a run starts there)
-        lead = prev != pos2;
-        const u32 mine = lead ? lane : 0u;
-        u32 first = mine;
-        LZ_WAVE_SCAN_U32(first, mine, lz_umax)                           // the last run start at or below the lane
-        src4 = first << 2;
-    }
-#if defined(LZ_SCAN_PLAIN_TARGET)        // A/B aid: the target windows from the plain arrays (1.5 lines per hit)
-    lz_lut_fetch<false, SP>(Q, pos1, diag, rawl); lz_lut_fetch<true, SP>(Q, pos1, diag, rawr);
-#else
-    {
-        // lz_lut_fetch's loads, the target's from the half-overlapping blocks: the left window starts at byte bl, the right
-        // one at br = bl + 15 or 16, together at most 32 bytes: one line of t2x (block bl / 32, offset bl % 32)
-        const u32 stl = pos1 - 1u + (u32)LZ_PAD2, str = pos1 + (u32)LZ_PAD2;
-        const u32 bl = (stl >> 2) - 15u, br = str >> 2;
-        const u32 ol = bl + (bl & ~31u);
-        rawl.tv = lz_load16(Q.t2x + ol); rawr.tv = lz_load16(Q.t2x + (ol + (br - bl)));
-        const u32 sql = stl - (u32)diag, sqr = str - (u32)diag;
-        if (lead) { rawl.qv = lz_load16(Q.q2 + ((sql >> 2) - 15u)); rawr.qv = lz_load16(Q.q2 + (sqr >> 2)); }
-        if constexpr (SP) {
-            const u32 ml = (stl >> 3) - 14u, mr = str >> 3;           // (mr - ml is 14 or 15: at most 31 bytes)
-            const u32 oml = ml + (ml & ~31u);
-            rawl.tm = lz_load16(Q.tspx + oml); rawr.tm = lz_load16(Q.tspx + (oml + (mr - ml)));
-            if (lead) { rawl.qm = lz_load16(Q.qsp + ((sql >> 3) - 14u)); rawr.qm = lz_load16(Q.qsp + (sqr >> 3)); }
-        }
-    }
-#endif
-#if defined(LZ_EXP_DOUBLE_QUERY)        // timing experiment (results unchanged): the query windows fetched TWICE -- the slow-down is what
-    {                                   // the lanes' own query loads cost (would sharing them across lanes of equal pos2 pay?)
-        const u32 stl = pos1 - 1u + (u32)LZ_PAD2, str = pos1 + (u32)LZ_PAD2;
-        const u32 sql = stl - (u32)diag, sqr = str - (u32)diag;
-        const u8* q2b = Q.q2; asm volatile("" : "+v"(q2b));             // (laundered: not the same pointer to the compiler)
-        const LzVec16 xl = lz_load16(q2b + ((sql >> 2) - 15u)), xr = lz_load16(q2b + (sqr >> 2));
-        asm volatile("" :: "v"(xl.w[0]), "v"(xl.w[1]), "v"(xl.w[2]), "v"(xl.w[3]), "v"(xr.w[0]), "v"(xr.w[1]), "v"(xr.w[2]), "v"(xr.w[3]));
-    }
-#endif
-#if defined(LZ_EXP_NO_LEFT_TARGET)      // timing experiments only (results are wrong): what the random target fetches cost
-    rawl.tv = rawr.tv;
-#elif defined(LZ_EXP_NO_TARGET)
-    rawl.tv = rawl.qv; rawr.tv = rawr.qv;
-#elif defined(LZ_EXP_LOCAL_TARGET)
-    { LzLutParams Q2 = Q; Q2.t2 = Q.t2 + (size_t)(blockIdx.x & 7u) * 1048576u; const u32 p1 = pos1 & 0x3FFFFFu;     // every XCD inside its own 1 MiB of the target
-      lz_lut_fetch<false, SP>(Q2, p1, (s32)(p1 - pos2), rawl); lz_lut_fetch<true, SP>(Q2, p1, (s32)(p1 - pos2), rawr); }
-#endif
-    return src4;
-}
-// ... and the hand-over: every lane takes the query windows of its run's first lane (a no-op for that lane itself)
-template <bool SP>
-__device__ __forceinline__ void lz_scan_share(u32 src4, LzLutRaw<SP>& rawl, LzLutRaw<SP>& rawr)
-{
-    if (!LZ_QSHARE) return;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        rawl.qv.w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)src4, (int)rawl.qv.w[k]);
-        rawr.qv.w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)src4, (int)rawr.qv.w[k]);
-    }
+    const u32 stl = pos1 - 1u + (u32)LZ_PAD2, str = pos1 + (u32)LZ_PAD2;
+    const u32 bl = (stl >> 2) - 15u, br = str >> 2;
+    const u32 ol = bl + (bl & ~31u);
+    rawl.tv = lz_load16(Q.t2x + ol); rawr.tv = lz_load16(Q.t2x + (ol + (br - bl)));
+    const u32 sql = stl - (u32)diag, sqr = str - (u32)diag;
+    rawl.qv = lz_load16(Q.q2 + ((sql >> 2) - 15u)); rawr.qv = lz_load16(Q.q2 + (sqr >> 2));
     if constexpr (SP) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            rawl.qm.w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)src4, (int)rawl.qm.w[k]);
-            rawr.qm.w[k] = (u32)__builtin_amdgcn_ds_bpermute((int)src4, (int)rawr.qm.w[k]);
-        }
+        const u32 ml = (stl >> 3) - 14u, mr = str >> 3;           // (mr - ml is 14 or 15: at most 31 bytes)
+        const u32 oml = ml + (ml & ~31u);
+        rawl.tm = lz_load16(Q.tspx + oml); rawr.tm = lz_load16(Q.tspx + (oml + (mr - ml)));
+        rawl.qm = lz_load16(Q.qsp + ((sql >> 3) - 14u)); rawr.qm = lz_load16(Q.qsp + (sqr >> 3));
     }
 }
 
@@ -978,7 +919,7 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
         u64 k0, k1, k2, k3;
         load_keys(span, k0, k1, k2, k3);
         LzLutRaw<SP> al, ar, bl, br;
-        u32 sa = lz_scan_fetch<SP>(Q, k0, al, ar, lane), sb = 0;
+        lz_scan_fetch<SP>(Q, k0, al, ar);
 #pragma unroll 1
         for (;;) {
             const u64 base = span * SPAN;
@@ -986,18 +927,14 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
             const u32 ib = (u32)base + lane;                     // (hit indices inside a chunk are 32-bit: lzgpu_set_hit_capacity)
             const bool more_spans = span + wstride < nspans;
             u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-            sb = lz_scan_fetch<SP>(Q, k1, bl, br, lane);
-            lz_scan_share<SP>(sa, al, ar);
+            lz_scan_fetch<SP>(Q, k1, bl, br);
             lz_scan_round<SP>(P, Q, lut, ctab, k0, lane < span_n, al, ar, ib, lane, summ, my_tasks, my_n, region_cap);
             if (more_spans) load_keys(span + wstride, n0, n1, n2, n3);
-            lz_scan_share<SP>(sb, bl, br);                      // (before set a is requested again: the crossbar reads the lanes' registers now)
-            sa = lz_scan_fetch<SP>(Q, k2, al, ar, lane);
+            lz_scan_fetch<SP>(Q, k2, al, ar);
             lz_scan_round<SP>(P, Q, lut, ctab, k1, lane + 64u < span_n, bl, br, ib + 64u, lane, summ, my_tasks, my_n, region_cap);
-            lz_scan_share<SP>(sa, al, ar);
-            sb = lz_scan_fetch<SP>(Q, k3, bl, br, lane);
+            lz_scan_fetch<SP>(Q, k3, bl, br);
             lz_scan_round<SP>(P, Q, lut, ctab, k2, lane + 128u < span_n, al, ar, ib + 128u, lane, summ, my_tasks, my_n, region_cap);
-            lz_scan_share<SP>(sb, bl, br);
-            if (more_spans) sa = lz_scan_fetch<SP>(Q, n0, al, ar, lane);
+            if (more_spans) lz_scan_fetch<SP>(Q, n0, al, ar);
             lz_scan_round<SP>(P, Q, lut, ctab, k3, lane + 192u < span_n, bl, br, ib + 192u, lane, summ, my_tasks, my_n, region_cap);
             if (!more_spans) break;
             span += wstride; k0 = n0; k1 = n1; k2 = n2; k3 = n3;

@@ -245,7 +245,7 @@ def merge_marked(texts, fmt="maf", rename=None):
     return (head or "") + body
 
 
-def check_supported(target, args):
+def check_supported(target, args, query=None):
     """what the merger cannot put back together is refused before any rank starts"""
     fmt = output_format(args)
     if fmt != "lav" and not line_oriented(fmt):
@@ -256,9 +256,19 @@ def check_supported(target, args):
             raise ValueError("lastz_amd.multi collects the ranks' standard output: %s is not supported" % a)
         # searches that do not go through the seed_hit_search hook carry no unit plan (every rank would compute
         # everything): anchors from a file, chore lists, quantum queries
-        if a.startswith("--segments=") or a.startswith("--chores=") or a.startswith("--anyornone") or "quantum" in a:
+        if a.startswith("--segments=") or a.startswith("--chores=") or a == "--anyornone" or a.startswith("--anyornone="):
             raise ValueError("lastz_amd.multi shards (query sequence, strand) units of the seed search: %s names work "
                              "that does not come as such units; run it through a single lastz_gpu process" % a)
+    # quantum DNA is marked on the sequence specifier (a [quantum] / [quantum=...] action, or a .qdna file), not by an option:
+    # a query that merely has "quantum" in its file name is an ordinary query
+    for spec in (target, query):
+        if spec is None:
+            continue
+        spath, sact = split_spec(spec)
+        actions = [x.strip() for grp in re.findall(r"\[([^\]]*)\]", sact) for x in grp.split(",")]
+        if spath.lower().endswith(".qdna") or any(x == "quantum" or x.startswith("quantum=") for x in actions):
+            raise ValueError("lastz_amd.multi shards (query sequence, strand) units of the seed search: the quantum sequence %s "
+                             "does not go through it; run it through a single lastz_gpu process" % spec)
     tpath, tact = split_spec(target)
     if "[multi]" not in tact and os.path.exists(tpath):
         with open(tpath, "rb") as f:
@@ -272,7 +282,7 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
         whole_sequences=None):
     """-> (merged LAV text, [stderr of each rank], plan).  After the call run.last holds {"rank_seconds": [...],
     "owned_bases": [...], "split": bool} of this run."""
-    check_supported(target, list(args))
+    check_supported(target, list(args), query)
     fmt = output_format(list(args))
     qpath, qact = split_spec(query)
     index = fasta_index(qpath)

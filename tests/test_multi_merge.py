@@ -113,3 +113,17 @@ def test_formats_the_launcher_takes_and_refuses(tmp_path):
     for bad in (["--format=rdotplot"], ["--format=text"], ["--format=lav+text"], ["--format=blastn"], ["--format=gfa"]):
         with pytest.raises(ValueError):
             multi.check_supported(str(t), bad)
+
+
+def test_quantum_is_read_off_the_sequence_specifier_not_off_a_substring(tmp_path):
+    """a query NAMED quantum_reads.fa is an ordinary query; [quantum] actions and .qdna files are refused"""
+    t = tmp_path / "t.fa"; t.write_text(">t\nACGT\n")
+    q = tmp_path / "quantum_reads.fa"; q.write_text(">q\nACGT\n")
+    multi.check_supported(str(t), ["--format=maf", "--output-note=quantum"], str(q))
+    multi.check_supported(str(t), [], str(q) + "[unmask]")
+    for bad in (str(q) + "[quantum]", str(q) + "[unmask][quantum=x.codes]", str(q) + "[unmask,quantum]", str(tmp_path / "reads.qdna")):
+        with pytest.raises(ValueError):
+            multi.check_supported(str(t), [], bad)
+    for bad in (["--anyornone"], ["--segments=x"], ["--chores=y"]):
+        with pytest.raises(ValueError):
+            multi.check_supported(str(t), bad, str(q))
