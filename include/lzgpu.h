@@ -297,6 +297,12 @@ typedef struct lz_chain_args {
     int32_t overlap_sub;
 } lz_chain_args;
 int lzgpu_reduce_to_chain(const lz_chain_args* a, const lz_segment* segs, uint32_t n, uint32_t** kept, uint32_t* n_kept, int32_t* best);
+/* k independent chaining problems (the strands of a query, the units a rank has searched) with the same penalties, each on a host
+ * thread of its own: a problem is serial by nature, a series of problems is not.  segs[j] / n[j] the anchors of problem j; kept / n_kept /
+ * best are arrays of k (best may be NULL), each kept[j] freed with lzgpu_free.  Results are those of k calls of lzgpu_reduce_to_chain.
+ * Like that call it never touches the device, so it may run on any host thread beside B2 / B3 calls. */
+int lzgpu_reduce_to_chain_batch(const lz_chain_args* a, const lz_segment* const* segs, const uint32_t* n, uint32_t k,
+                                uint32_t** kept, uint32_t* n_kept, int32_t* best);
 
 typedef struct lz_counters {       /* same events as the reference's collect_stats build          */
     uint64_t words;                /* "words in seq 2"    src/seed_search.c:514                   */

@@ -423,6 +423,20 @@ postable* build_seed_position_table
 	if ((mgWorld > 1) || (getenv ("LZGPU_SHARE_FORCE") != NULL))
 		{
 		char dir[1024];                                            /* one rendezvous directory per table of the run */
+		if (mgTables == 0)
+			{
+			/* start-up self-check of a multi-process run: this rank's library is bound to the device the launcher gave it
+			   (LOCAL_RANK), or the run stops here -- a rank that lands on another rank's device would still produce the
+			   right bytes, slowly, on a GPU that is not its own.  The line below is what the launcher checks. */
+			char* lr = getenv ("LOCAL_RANK");
+			int   dev;
+			rc = lzgpu_init (-1);
+			if (rc != 0) suicidef ("lzgpu_init: %s", lzgpu_last_error());
+			dev = lzgpu_device_index ();
+			fprintf (stderr, "[lzgpu] rank %d of %d: device %d\n", mgRank, mgWorld, dev);
+			if ((lr != NULL) && (dev != atoi (lr)))
+				suicidef ("rank %d is bound to device %d but LOCAL_RANK=%s (fewer visible devices than ranks?)", mgRank, dev, lr);
+			}
 		snprintf (dir, sizeof(dir), "%s/table%d", mgDir, mgTables++);
 		if ((mgRank == 0) && (mkdir (dir, 0700) != 0) && (errno != EEXIST)) suicidef ("cannot create %s: %s", dir, strerror (errno));
 		rc = lzgpu_table_share (mgRank, mgWorld, dir);

@@ -23,6 +23,9 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <system_error>
 #include "lz_common.hpp"
 #include "../../include/lzgpu.h"
 
@@ -197,5 +200,42 @@ extern "C" int lzgpu_reduce_to_chain(const lz_chain_args* a, const lz_segment* s
         if (b > (bigscore)0x7FFFFFFF) b = (bigscore)0x7FFFFFFF;
         *best_out = (s32)b;
     }
+    return 0;
+}
+
+
+// Several independent chaining problems -- the two strands of a query, the units a rank has finished searching -- at once, one host
+// thread each (at most `LZGPU_CHAIN_THREADS`, default 16).  A problem is serial by nature (every anchor needs the finished scores of all
+// earlier ones); what need not be serial is one problem after the other: --chain on a 200 Mbp pair is 90 ms per strand, and the two
+// strands' chains -- or a unit's chain and the next unit's search on the device -- do not wait for each other.
+// Results are those of k calls of lzgpu_reduce_to_chain; the return code is that of the first problem that did not return 0.
+extern "C" int lzgpu_reduce_to_chain_batch(const lz_chain_args* a, const lz_segment* const* segs, const uint32_t* n, uint32_t k,
+                                           uint32_t** kept, uint32_t* n_kept, int32_t* best)
+{
+    if (!a || !segs || !n || !kept || !n_kept || k == 0) return lz_fail(LZGPU_ERR_ARG, "lzgpu_reduce_to_chain_batch: null argument");
+    for (u32 j = 0; j < k; j++) { kept[j] = nullptr; n_kept[j] = 0; if (best) best[j] = 0; }
+    static const u32 cap = []() { const char* e = getenv("LZGPU_CHAIN_THREADS"); const int v = e ? atoi(e) : 0; return (u32)(v > 0 ? v : 16); }();
+    std::vector<int> rcs(k, 0);
+    std::atomic<u32> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const u32 j = next.fetch_add(1);
+            if (j >= k) break;
+            rcs[j] = lzgpu_reduce_to_chain(a, segs[j], n[j], &kept[j], &n_kept[j], best ? &best[j] : nullptr);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        const u32 want = k < cap ? k : cap;
+        try { for (u32 t = 1; t < want; t++) th.emplace_back(work); }
+        catch (const std::system_error&) { /* fewer helpers than asked for: the ones that started, and this thread, do the work */ }
+        work();
+        for (auto& t : th) t.join();
+    }
+    for (u32 j = 0; j < k; j++)
+        if (rcs[j]) {
+            for (u32 i = 0; i < k; i++) { free(kept[i]); kept[i] = nullptr; n_kept[i] = 0; }
+            return rcs[j];
+        }
     return 0;
 }

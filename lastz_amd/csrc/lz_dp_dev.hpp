@@ -35,7 +35,9 @@
 #define LZ_DP_LANES   256             // lanes (threads) per one-sided DP: 4 waves of one workgroup
 #endif
 #define LZ_DP_WAVES   (LZ_DP_LANES / 64)
+#ifndef LZ_DP_MAXW
 #define LZ_DP_MAXW    2048            // ring size (columns) of the sweep row held in LDS
+#endif
 #define LZ_DP_WIDEW   65536           // ... of the wide variant, whose ring lives in HBM (bands the LDS ring cannot hold)
 #define LZ_DP_TBWIN   64              // traceback look-ahead window (links along one diagonal)
 #define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks

@@ -69,7 +69,7 @@ EXPORTS = ["lzgpu_seed_from_pattern", "lzgpu_probe", "lzgpu_init", "lzgpu_device
            "lzgpu_seed_hit_search", "lzgpu_query_upload", "lzgpu_target_upload", "lzgpu_gapped_extend", "lzgpu_gapped_extend_batch", "lzgpu_window_search",
            "lzgpu_counters_reset", "lzgpu_counters_get", "lzgpu_profile_enable", "lzgpu_profile_reset",
            "lzgpu_profile_get", "lzgpu_set_hit_capacity", "lzgpu_set_hsp_capacity", "lzgpu_set_dp_slot", "lzgpu_set_dp_window", "lzgpu_dp_longest",
-           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode", "lzgpu_reduce_to_chain"]
+           "lzgpu_set_bucket_owner", "lzgpu_last_hsp_order", "lzgpu_last_scan_mode", "lzgpu_set_scan_mode", "lzgpu_reduce_to_chain", "lzgpu_reduce_to_chain_batch"]
 
 
 class LzGpuError(RuntimeError):
@@ -140,6 +140,10 @@ class Lib:
 
     def probe(self):
         return self.L.lzgpu_probe()
+
+    def device_index(self):
+        """the device this process's library is bound to (-1 before init)"""
+        return int(self.L.lzgpu_device_index())
 
     def shutdown(self):
         self.L.lzgpu_shutdown()
@@ -321,6 +325,24 @@ class Lib:
             C.memmove(out.ctypes.data, kept, 4 * n.value)
         self.L.lzgpu_free(kept)
         return out, best.value
+
+    def reduce_to_chain_batch(self, anchor_sets, chain_diag=0, chain_anti=0, scale=100, overlap_sub=91, diag_pen=None, anti_pen=None):
+        """several (query, strand) problems at once, one host thread each -> [(kept indices, chain score)] as reduce_to_chain gives them"""
+        sets = [np.ascontiguousarray(x, dtype=SEG_DTYPE) for x in anchor_sets]
+        k = len(sets)
+        a = (C.c_int32 * 6)(chain_diag if diag_pen is None else diag_pen, chain_anti if anti_pen is None else anti_pen,
+                            chain_diag, chain_anti, scale, overlap_sub)
+        ptrs = (C.c_void_p * k)(*[x.ctypes.data for x in sets]); ns = (C.c_uint32 * k)(*[len(x) for x in sets])
+        kept = (C.c_void_p * k)(); nk = (C.c_uint32 * k)(); best = (C.c_int32 * k)()
+        self._check(self.L.lzgpu_reduce_to_chain_batch(a, ptrs, ns, C.c_uint32(k), kept, nk, best), "lzgpu_reduce_to_chain_batch")
+        res = []
+        for j in range(k):
+            out = np.zeros(nk[j], dtype=np.uint32)
+            if nk[j]:
+                C.memmove(out.ctypes.data, kept[j], 4 * nk[j])
+            self.L.lzgpu_free(kept[j])
+            res.append((out, best[j]))
+        return res
 
     # ---- B1 + B2 of many windows (N3)
     def window_search(self, masked_sub, windows, sd, ctb, q=None, slot=-1, xdrop=910, hsp_threshold=3000):

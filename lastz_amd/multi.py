@@ -333,7 +333,15 @@ def run(target, query, args=(), ranks=2, lastz=DEFAULT_LASTZ, devices=None, tran
         bad = [r for r, p in enumerate(procs) if p.returncode != 0 and p.returncode != -9] or [r for r, p in enumerate(procs) if p.returncode != 0]
         if bad:
             raise RuntimeError("rank %d failed (rc %d): %s" % (bad[0], procs[bad[0]].returncode, errs[bad[0]][-2000:]))
-        run.last = {"rank_seconds": secs, "owned_bases": [sum(lengths[i] for i in {qi for qi, _ in p}) for p in plan], "split": split}
+        # start-up self-check (the shim prints the device every rank bound itself to, and stops the run if it is not the one it was given)
+        bound = []
+        for r in range(ranks):
+            m = re.search(r"\[lzgpu\] rank %d of %d: device (\d+)" % (r, ranks), errs[r])
+            bound.append(int(m.group(1)) if m else None)
+        want = [devices[r] if devices else r for r in range(ranks)]
+        if ranks > 1 and any(b is not None and b != w for b, w in zip(bound, want)):
+            raise RuntimeError("device binding self-check failed: ranks bound to devices %r, the launcher assigned %r" % (bound, want))
+        run.last = {"devices_bound": bound, "rank_seconds": secs, "owned_bases": [sum(lengths[i] for i in {qi for qi, _ in p}) for p in plan], "split": split}
         rename = [(qfiles[r], qpath) for r in range(ranks)]
         merged = merge_lav(outs, rename) if fmt == "lav" else merge_marked(outs, fmt, rename)
         return merged, errs, plan

@@ -54,6 +54,22 @@ def test_order_of_the_input_does_not_matter_and_the_output_is_in_pos1_order(lib,
         assert (np.diff(p2.astype(np.int64)) > 0).all()
 
 
+def test_a_batch_of_problems_is_the_problems_one_by_one(lib, vectors):
+    """lzgpu_reduce_to_chain_batch: every problem on a host thread of its own (VERDICT r4 #6) -- the same kept sets, the same scores"""
+    by_pen = {}
+    for c in vectors["cases"]:
+        by_pen.setdefault((c["chain_diag"], c["chain_anti"]), []).append(c)
+    for (d, a), cases in by_pen.items():
+        sets = [segs(vectors["sets"][c["set"]]["anchors"]) for c in cases]
+        got = lib.reduce_to_chain_batch(sets, d, a, vectors["scale"], vectors["overlap_sub"])
+        assert len(got) == len(cases)
+        for c, s, (kept, best) in zip(cases, sets, got):
+            assert sorted(int(k) for k in kept) == c["kept"]
+            one_kept, one_best = lib.reduce_to_chain(s, d, a, vectors["scale"], vectors["overlap_sub"])
+            assert list(one_kept) == list(kept) and one_best == best
+    assert lib.reduce_to_chain_batch([np.zeros(0, dtype=lzgpu.SEG_DTYPE), segs([(5, 9, 20, 3100)])])[1][1] == 3100
+
+
 def test_score_of_the_chain(lib):
     """three anchors on one diagonal, no penalties: the chain is all of them and scores their sum; an overlap costs
     overlap_sub per overlapped base (src/lastz.c:3728-3733), which makes the overlapping one not worth taking"""

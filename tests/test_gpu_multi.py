@@ -157,7 +157,26 @@ def test_bench_two_ranks_search_and_gapped_stage_equal_one_rank():
     assert kinds == {"search", "gapped"}
     for r in two["per_rank"]:
         assert r["search_s"] > 0 and r["gapped_s"] > 0
+        assert 1 <= r["b3_batches"] <= 2                        # three units of a rank: the strands of a sequence go down together (VERDICT r4 #5b)
     assert 0 < two["table_build_and_broadcast_share_of_step"] < 1
+    # start-up self-check (VERDICT r4 #5c): every rank's library on the device of its LOCAL_RANK; here the two ranks share the one device by design
+    for line in (one, two):
+        sc = line["device_selfcheck"]
+        assert sc["ok"] and all(e["lzgpu_device_index"] == e["local_rank"] for e in sc["ranks"])
+    assert two["device_selfcheck"]["ranks_share_a_device"] or two["device_selfcheck"]["devices_visible"] >= 2
+
+
+def test_bench_chain_in_front_of_the_gapped_stage_on_the_b3_thread():
+    """configs[4]'s shape: --chain -- every unit's HSPs chained (lzgpu_reduce_to_chain_batch, host code on the B3 thread beside the next
+    unit's search), the chains extended; two ranks = one rank, and the chained job extends fewer anchors into fewer alignments"""
+    two = _bench(["--gpus", "2", "--chain"] + SHAPE, 2, 29545)
+    one = _bench(["--gpus", "1", "--force-multi", "--chain"] + SHAPE, 1, 0)
+    plain = _bench(["--gpus", "1", "--force-multi"] + SHAPE, 1, 0)
+    assert two["chain"] and one["chain"] and not plain["chain"]
+    assert two["alignments_sha"] == one["alignments_sha"] != plain["alignments_sha"]
+    assert 0 < one["alignments"] <= plain["alignments"]
+    assert one["hsps_merged"] == plain["hsps_merged"]
+    assert all(r["chain_s_inside_gapped_s"] > 0 for r in two["per_rank"])
 
 
 def test_bench_bucket_owners_inside_the_units():
