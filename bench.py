@@ -6,25 +6,36 @@ N = 1 (the driver's bench line): workload = BASELINE.json configs[1]: synthetic 
 hot path over the batch, inputs already resident in HBM: position-table build from the resident target (B1), then
 seed-hit search + X-drop extension of the + strand and of the - strand of the query (B2), HSPs delivered to the host in
 the reference's order.  After the timed steps the same process adds, outside `value`:
-  gapped    configs[2]: the same pair through the Y-drop DP (B3, --ydrop=9430): GCUPS, k_ydrop time, DP cpu_baseline
-  parity    SHA-256 of the HSP list and of the LAV the lastz CLI bound to this library writes for this exact pair,
-            against the fingerprints of the pristine reference's output (tests/golden/bench50m.sha.json, made by
-            tests/golden/make_bench_sha.py: 2 x 40 minutes of CPU) -- and the CLI's wall clock
-  chain     N2: lzgpu_reduce_to_chain (a host routine) on the pair's HSPs, strand by strand: its clock
-  cli       the bound lastz on the pair, four runs back to back: first after this process freed its device memory, median, minimum
-  north_star  the same legs on BASELINE.json's north-star pair (200 Mbp x 200 Mbp): seed stage (1 warm-up + 2 timed steps), gapped
-            batch, chain clock, one CLI run, parity against tests/golden/bench200m.sha.json (--no-north-star skips it)
+  roofline  k_scan_hits: algorithmic bytes / HIP-event time; `traffic` from THIS run's own rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE,
+            one pass each over a child process that runs one step), calibrated with the factors tools/fetch_calib.sh measured on known
+            byte counts (profiles/fetch_size_calibration.json); --no-pmc replays the committed table instead and says so
+  gapped    configs[2]: the same pair through the Y-drop DP (B3, --ydrop=9430): GCUPS, k_ydrop time, its HBM evidence (`roofline`, with PMC
+            traffic) and the ceiling it is graded against (`roofline_int_alu`), DP cpu_baseline
+  parity    SHA-256 of the HSP list, of the alignments the batch DP returned written out as a LAV (lastz_amd/lav.py), and of the LAV the
+            lastz CLI bound to this library writes for this exact pair, against the fingerprints of the pristine reference's output
+            (tests/golden/bench50m.sha.json, made by tests/golden/make_bench_sha.py: 2 x 40 minutes of CPU); the batch's alignments
+            against the CLI's LAV field by field -- and the CLI's wall clock
+  chain     N2: lzgpu_reduce_to_chain_batch (host code) on the pair's HSPs, both strands side by side; one after the other; beside a gapped batch
+  cli       the bound lastz on the pair, four runs back to back (first after this process freed its device memory, median, minimum) and
+            one after a pause (the definition rounds 1-3 quoted)
+  north_star  the same legs on BASELINE.json's north-star pair (200 Mbp x 200 Mbp): seed stage (1 warm-up + 3 timed steps: mean, min,
+            median), its own PMC passes, gapped batch, chain clock, one CLI run, parity against tests/golden/bench200m.sha.json
+            (--no-north-star skips it)
   content   the seed stage on the same pair with 40 % soft-masked bases + N runs, and with sparse IUPAC codes (scan mode 1)
   cpu_baseline  the pristine reference binary on the box's host cores: 1 core (lastz is single-threaded) and the whole
-            host (one process per core over query units, the reference's own scale-out model), on a bounded sample
+            host (one process per core over query units, the reference's own scale-out model), on a bounded sample SCALED to the bench
+            size (`scaled_sample`), with the reference's full-size wall on this pair (clocked once, on another box) beside it
 
 N > 1 (one process per GPU, torch.distributed / RCCL): workload = BASELINE.json configs[3] in its shape: 200 Mbp target
 against 15 query sequences x 2 strands = 30 units, LPT-sharded over the ranks (strong scaling: the job is fixed), the
 position table built on rank 0 and broadcast over RCCL/xGMI once per job; every rank searches its units AND runs their gapped
-stage (--ydrop=9430), unit k's on a second host thread and stream beside unit k + 1's search; HSP lists and alignment digests
-gathered and merged on rank 0 in the reference's order.  A step = the whole job.  (--q-unit-len / --q-units / --tlen-multi scale
-it for smoke runs; --bucket-owners splits every unit's search over the ranks by hashed-diagonal ownership; --force-multi runs
-this code path on one rank.)
+stage (--ydrop=9430) on a second host thread and stream beside the next units' searches, the finished units going down in batches
+(lzgpu_gapped_extend_batch; --chain: their HSPs chained first, configs[4]'s shape); HSP lists and alignment digests
+gathered and merged on rank 0 in the reference's order.  A step = the whole job.  Before any work every rank checks that its library is
+on the device of its LOCAL_RANK and that device 0 was left alone by the others (device_selfcheck).  At configs[3]'s own sizes unit 0 is
+the north-star query and its HSP list is checked against the reference's fingerprint inside the line (north_star_unit).
+(--q-unit-len / --q-units / --tlen-multi scale it for smoke runs; --bucket-owners splits every unit's search over the ranks by
+hashed-diagonal ownership; --force-multi runs this code path on one rank: the N = 1 point of the curve.)
 
 One JSON line on rank 0 (driver contract); extra objects: roofline, cpu_baseline, gapped, chain, parity, cli, north_star, content.
 """
