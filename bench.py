@@ -145,11 +145,13 @@ def pmc_live(child_args, timeout_s=240):
     return out
 
 
-def traffic_fields(kernel, pmc, gather=True):
+def traffic_fields(kernel, pmc, gather=True, stream_bytes=0.0):
     """the roofline object's traffic keys for `kernel`: live PMC (this run) if there is one, else the committed table, else null.
     traffic = bytes per launch as counted (FETCH_SIZE + WRITE_SIZE); traffic_calibrated = the same with the factors measured for this
-    kernel's access patterns on known byte counts (pmc_calibration) -- NOT the guide's x2 for wide streaming reads, which does not apply
-    to 16-byte gathers."""
+    kernel's access patterns on known byte counts (pmc_calibration): on gfx950 a coalesced stream is counted at HALF its bytes whether its
+    loads are 16 or 8 bytes wide (factor 2.00), a 16-byte gather at the 64-byte line it moves (0.98-1.00), stores as they are (1.00).  So
+    the guide's x2 applies to the kernel's coalesced key stream (`stream_bytes` per launch, known: 8 bytes per hit) and NOT to its window
+    gathers -- round 4's blanket x2 implied 7 TB/s."""
     src = None
     e = (pmc or {}).get(kernel) or (pmc or {}).get(kernel + "2")          # (k_fill_hits2 is timed as k_fill_hits)
     if e and "fetch" in e and "write" in e:
@@ -166,8 +168,10 @@ def traffic_fields(kernel, pmc, gather=True):
     if cal:
         ff = cal["fetch_gather16"] if gather else cal["fetch_stream16"]
         fw = cal["write_store4_nt"] if gather else cal["write_store8_nt"]
-        if ff and fw:
-            calibrated = e["fetch"] * ff + e["write"] * fw
+        fs = cal["fetch_stream8_nt"]
+        if ff and fw and fs:
+            counted_stream = min(stream_bytes / fs, e["fetch"])          # what the counter shows of the coalesced stream
+            calibrated = (e["fetch"] - counted_stream) * ff + counted_stream * fs + e["write"] * fw
     return {"traffic": calibrated if calibrated is not None else counted, "traffic_counted": counted, "traffic_calibrated": calibrated,
             "traffic_fetch_counted": e["fetch"], "traffic_write_counted": e["write"], "traffic_launches_in_pmc_pass": e.get("launches"),
             "traffic_calibration": cal, "traffic_source": src}
@@ -316,7 +320,7 @@ def seed_roofline(prof, cnt, K, num_probes, dt, pmc=None):
     avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
     ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, **traffic_fields(dom, pmc),
+            "frac": ach / HBM_PEAK_GBS, **traffic_fields(dom, pmc, stream_bytes=(8.0 * Hh / launches) if dom == "k_scan_hits" else 0.0),
             "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
             "launches_per_step": launches,
             # whole seed stage against the same roofline, on wall time
@@ -522,7 +526,12 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
 def attach_traffic(rec, pmc):
     """the PMC bytes of this run's own passes (pmc_live) into the roofline objects of a measure_pair record"""
     if rec.get("roofline"):
-        rec["roofline"].update(traffic_fields(rec["roofline"]["kernel"], pmc))
+        r = rec["roofline"]
+        hits_per_launch = rec["counters_per_step"]["raw_hits"] / max(r["launches_per_step"], 1.0)
+        r.update(traffic_fields(r["kernel"], pmc, stream_bytes=8.0 * hits_per_launch if r["kernel"] == "k_scan_hits" else 0.0))
+        if r.get("traffic"):
+            r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
+            r["traffic_GBs"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
     g = rec.get("gapped")
     if g:
         e = (pmc or {}).get("k_ydrop")
