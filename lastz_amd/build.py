@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.environ.get("LZGPU_CSRC") or os.path.join(HERE, "csrc")      # (LZGPU_CSRC: a patched copy of the sources, tools/build_variant.sh)
 OUT = os.path.join(HERE, "liblzgpu.so")
-SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "window_kernels.hip", "lz_share.hip", "lz_host.cpp", "lz_gapped_host.cpp", "lz_chain_host.cpp"]
+SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "window_kernels.hip", "lz_share.hip", "lz_host.cpp", "lz_gapped_host.cpp", "lz_dp_pieces.cpp", "lz_chain_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("LZGPU_CXXFLAGS", "").split()
 
 

@@ -159,8 +159,9 @@ struct GpuPhases {                      // X for lz_dp_run: one thread = one lan
 };
 
 #ifndef LZ_DP_WPE
-#define LZ_DP_WPE 5                    // waves per SIMD the register allocation must allow: five DPs of four waves per CU (six fit the LDS, but at 80
-                                       // registers the kernel with bounds spilled 15-44 of them once the walks carried their cells in registers)
+#define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow for the kernel with bounds: six DPs of four waves per CU, what its
+                                       // 25 KiB of LDS hold (round 4 ran five: with the bounds and the active segments walked on the device it needed 87-91
+                                       // registers; reading pieces it takes 57)
 #endif
 #ifndef LZ_DP_WPE_FREE
 #define LZ_DP_WPE_FREE 7               // ... and seven of the problems without earlier alignments (no mask stamps: 22 KiB per DP)
@@ -181,9 +182,9 @@ k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* _
     GpuPhases x;
     x.lead_wave = (int)((blockIdx.x + (blockIdx.x >> 8)) & (LZ_DP_WAVES - 1));
     const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
-    const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its snapshot, its query)
+    const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its query, its window of the sequences)
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM, BOUNDS, REPLICATE>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS, REPLICATE>(x, sh, P, J, tab, &res[j]);
 }
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
@@ -203,7 +204,7 @@ k_ydrop_wide(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJ
     const LzDpJob J = jobs[j];
     const LzDpProblem pb = problems[J.problem];
     P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM, BOUNDS, false>(x, sh, pb.S, P, J, tab, &res[j]);
+    lz_dp_run<NOTRIM, BOUNDS, false>(x, sh, P, J, tab, &res[j]);
 }
 
 // gather the edit ops of a batch into one contiguous buffer (one block per job)
@@ -219,12 +220,12 @@ k_gather_ops(const LzDpJob* __restrict__ jobs, const LzDpResult* __restrict__ re
 }
 
 struct DpBufs {
-    DevBuf aligns, segs, obi, oed, jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, act, rings, sel_jobs, sel_res, problems;
+    DevBuf jobs, ids, res, tab, tb, rows, ops, ops_off, ops_out, pieces, rings, sel_jobs, sel_res, problems;
 };
 static DpBufs g_dp;
 void lz_dp_release_statics()
 {
-    DevBuf* b[] = { &g_dp.aligns, &g_dp.segs, &g_dp.obi, &g_dp.oed, &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.act, &g_dp.rings, &g_dp.sel_jobs, &g_dp.sel_res, &g_dp.problems };
+    DevBuf* b[] = { &g_dp.jobs, &g_dp.ids, &g_dp.res, &g_dp.tab, &g_dp.tb, &g_dp.rows, &g_dp.ops, &g_dp.ops_off, &g_dp.ops_out, &g_dp.pieces, &g_dp.rings, &g_dp.sel_jobs, &g_dp.sel_res, &g_dp.problems };
     for (DevBuf* x : b) x->release();
 }
 
@@ -247,7 +248,9 @@ struct HipDpExec : LzDpExecutor {
     double t_upload = 0, t_kernel = 0, t_ops = 0;               // LZGPU_HOSTPROF: host milliseconds in launch() / fetch_ops()
     u32 tab_rows = LZ_NCLASS;                                  // row classes of the score matrix in use (k_ydrop's dynamic LDS)
     const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
-    bool bounds = true;                                         // some problem of the launch has earlier alignments (else: k_ydrop<.., false>)
+    const std::vector<LzDpBatchItem>* cur_items = nullptr;     // ... and their snapshots on the host: what a job's pieces are worked out from
+    std::vector<u32> horizon;                                   // per job of the run: rows its pieces are asked for (grows when a sweep passes it)
+    u64 piece_reruns = 0, jobs_bounded = 0, jobs_free = 0;
     // Traceback slots.  A retry gives every DP the same (larger) slot; the first try sizes each DP's slot from the
     // host's guess of the rows it will sweep (est_rows, lz_gapped_host.cpp: the deferred anchors around the DP's
     // anchor): on the bench pair rows = 1.2 x est_rows (median; 2.2 x at the 90th percentile) and a row has ~430
@@ -272,8 +275,27 @@ struct HipDpExec : LzDpExecutor {
             J.tb_off = tb_total; J.tb_cap = (u32)sl;        tb_total += sl;
             J.row_off = row_total; J.row_cap = row_cap;     row_total += row_cap;
             J.ops_off = ops_total; J.ops_cap = ops_cap;     ops_total += ops_cap;
-            J.act_off = k * (u64)(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
         }
+        // The jobs' pieces (lz_dp_pieces.cpp): what earlier alignments mean for each sweep -- its left and right bound and the cells it
+        // must mask, as run-length pieces of rows -- worked out here, on the host, from the job's problem's snapshot, up to the job's
+        // horizon.  A job with no piece at all and none to come (the first round of a strand; a DP far from every alignment) needs no
+        // bound logic: those go to the kernel without it (no mask stamps in its ring: seven DPs per CU), the others to the one with it.
+        std::vector<LzDpPiece> arena;
+        std::vector<u32> ids_free, ids_bound;
+        {
+            LzDpPieces pcs;
+            for (u64 k = 0; k < n; k++) {
+                LzDpJob& J = jobs[ids[k]];
+                lzh_dp_pieces(*(*cur_items)[J.problem].snap, J, horizon[ids[k]], pcs);
+                J.pc_off = arena.size(); J.n_lb = (u32)pcs.lb.size(); J.n_rb = (u32)pcs.rb.size(); J.n_mk = (u32)pcs.mk.size();
+                J.horizon = pcs.complete ? 0xFFFFFFFFu : horizon[ids[k]];
+                arena.insert(arena.end(), pcs.lb.begin(), pcs.lb.end()); arena.insert(arena.end(), pcs.rb.begin(), pcs.rb.end()); arena.insert(arena.end(), pcs.mk.begin(), pcs.mk.end());
+                const bool free_job = pcs.complete && !J.n_lb && !J.n_rb && !J.n_mk;
+                (free_job && !wide ? ids_free : ids_bound).push_back(ids[k]);
+            }
+            if (arena.size() > (1u << 27)) return LZGPU_NH_UNSUPPORTED;          // (2 GiB of pieces for one launch: not a workload this path is for)
+        }
+        jobs_free += ids_free.size(); jobs_bounded += ids_bound.size();
         // a quarter of head room: the launches of a run (two strands, the rounds of a strand) differ a little, and a
         // buffer that grows is freed and allocated again -- 18 GiB of fresh device memory cost the second strand of
         // the 50 Mbp CLI run a second (tools/cli_prof.sh)
@@ -281,35 +303,43 @@ struct HipDpExec : LzDpExecutor {
         if (tb_total > g_dp.tb.cap && (rc = g_dp.tb.ensure(room(tb_total)))) return rc;
         if (row_total * 4 > g_dp.rows.cap && (rc = g_dp.rows.ensure(room(row_total * 4)))) return rc;
         if (ops_total * 4 > g_dp.ops.cap && (rc = g_dp.ops.ensure(room(ops_total * 4)))) return rc;
-        const u64 na = (n + 511) / 512 * 512;
-        if ((rc = g_dp.act.ensure((size_t)na * (LZ_DP_MAXACT - LZ_DP_ACT_LDS) * sizeof(LzDpActive)))) return rc;
+        if ((arena.size() + 1) * sizeof(LzDpPiece) > g_dp.pieces.cap && (rc = g_dp.pieces.ensure(room((arena.size() + 1) * sizeof(LzDpPiece))))) return rc;
         if ((rc = g_dp.jobs.ensure(jobs.size() * sizeof(LzDpJob)))) return rc;
         if ((rc = g_dp.ids.ensure(n * 4))) return rc;
         if ((rc = g_dp.res.ensure(jobs.size() * sizeof(LzDpResult)))) return rc;
+        std::vector<u32> ids_dev(ids_free); ids_dev.insert(ids_dev.end(), ids_bound.begin(), ids_bound.end());      // the two kernels' shares, back to back
+        if (!arena.empty()) LZ_HIP(hipMemcpyAsync(g_dp.pieces.p, arena.data(), arena.size() * sizeof(LzDpPiece), hipMemcpyHostToDevice, c.dp_stream));
         LZ_HIP(hipMemcpyAsync(g_dp.jobs.p, jobs.data(), jobs.size() * sizeof(LzDpJob), hipMemcpyHostToDevice, c.dp_stream));
-        LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids.data(), n * 4, hipMemcpyHostToDevice, c.dp_stream));
+        LZ_HIP(hipMemcpyAsync(g_dp.ids.p, ids_dev.data(), n * 4, hipMemcpyHostToDevice, c.dp_stream));
         P.tb_arena = g_dp.tb.as<u8>(); P.row_arena = g_dp.rows.as<u32>(); P.ops_arena = g_dp.ops.as<u32>();
-        P.act_arena = g_dp.act.as<LzDpActive>();
+        P.pc_arena = g_dp.pieces.as<LzDpPiece>();
         const auto lt1 = std::chrono::steady_clock::now();
         t_upload += std::chrono::duration<double, std::milli>(lt1 - lt0).count();
         if (wide) {
             if ((rc = g_dp.rings.ensure((size_t)n * LzDpRingHbm::SLOT_BYTES))) return rc;
             wide_runs += n;
             c.dp_timer.begin("k_ydrop_wide", c.dp_stream);
-            hipLaunchKernelGGL(P.no_trim ? (bounds ? k_ydrop_wide<true, true> : k_ydrop_wide<true, false>) : (bounds ? k_ydrop_wide<false, true> : k_ydrop_wide<false, false>),
-                               dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.dp_stream,
+            auto wkern = P.no_trim ? k_ydrop_wide<true, true> : k_ydrop_wide<false, true>;
+            hipLaunchKernelGGL(wkern, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
             c.dp_timer.begin("k_ydrop", c.dp_stream);
-            // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
-            // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
-            bool repl = !bounds && n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
-            if (const char* e = getenv("LZGPU_DP_REPL")) repl = !bounds && e[0] == '1';      // tests / A-B: force one or the other
-            auto kern = P.no_trim ? (bounds ? k_ydrop<true, true, false> : repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>)
-                                  : (bounds ? k_ydrop<false, true, false> : repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
             static const size_t pad_lds = []() { const char* e = getenv("LZGPU_DP_PAD_LDS"); return (size_t)(e ? atol(e) : 0); }();   // occupancy experiments: fewer DPs per CU
-            hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(LZ_DP_LANES), (size_t)tab_rows * LZ_NCLASS * sizeof(s32) + pad_lds, c.dp_stream,
-                               problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
+            const size_t dyn_lds = (size_t)tab_rows * LZ_NCLASS * sizeof(s32) + pad_lds;
+            if (!ids_free.empty()) {
+                // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
+                // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
+                bool repl = n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
+                if (const char* e = getenv("LZGPU_DP_REPL")) repl = e[0] == '1';                 // tests / A-B: force one or the other
+                auto kern = P.no_trim ? (repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>) : (repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
+                hipLaunchKernelGGL(kern, dim3((unsigned)ids_free.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
+                                   problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
+            }
+            if (!ids_bound.empty()) {
+                auto bkern = P.no_trim ? k_ydrop<true, true, false> : k_ydrop<false, true, false>;
+                hipLaunchKernelGGL(bkern, dim3((unsigned)ids_bound.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
+                                   problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
+            }
         }
         c.dp_timer.end(c.dp_stream);
         LZ_HIP(hipGetLastError());
@@ -397,33 +427,22 @@ struct HipDpExec : LzDpExecutor {
     int run_multi(std::vector<LzDpBatchItem>& items)
     {
         int rc;
-        // ---- the snapshots, back to back; a problem's indices stay relative to its own arrays
-        size_t na = 0, ns = 0, nj = 0;
-        for (auto& it : items) { na += it.snap->aligns.size(); ns += it.snap->segs.size(); nj += it.jobs->size(); }
-        if ((rc = g_dp.aligns.ensure((na ? na : 1) * sizeof(LzDpAlign)))) return rc;
-        if ((rc = g_dp.segs.ensure((ns ? ns : 1) * sizeof(LzDpSeg)))) return rc;
-        if ((rc = g_dp.obi.ensure((na ? na : 1) * 4))) return rc;
-        if ((rc = g_dp.oed.ensure((na ? na : 1) * 4))) return rc;
+        // ---- the problems of the launch: their queries / windows on the device; their snapshots stay on the host (launch(): pieces)
+        size_t nj = 0;
+        for (auto& it : items) nj += it.jobs->size();
         if ((rc = g_dp.problems.ensure(items.size() * sizeof(LzDpProblem)))) return rc;
         std::vector<LzDpProblem> pb(items.size());
         std::vector<LzDpJob> jobs; jobs.reserve(nj);
-        size_t oa = 0, os = 0;
         for (size_t p = 0; p < items.size(); p++) {
-            const LzHostSnapshot& snap = *items[p].snap;
-            const size_t a = snap.aligns.size(), g = snap.segs.size();
-            if (a) {
-                LZ_HIP(hipMemcpyAsync(g_dp.aligns.as<LzDpAlign>() + oa, snap.aligns.data(), a * sizeof(LzDpAlign), hipMemcpyHostToDevice, c.dp_stream));
-                LZ_HIP(hipMemcpyAsync(g_dp.obi.as<s32>() + oa, snap.obi.data(), a * 4, hipMemcpyHostToDevice, c.dp_stream));
-                LZ_HIP(hipMemcpyAsync(g_dp.oed.as<s32>() + oa, snap.oed.data(), a * 4, hipMemcpyHostToDevice, c.dp_stream));
-            }
-            if (g) LZ_HIP(hipMemcpyAsync(g_dp.segs.as<LzDpSeg>() + os, snap.segs.data(), g * sizeof(LzDpSeg), hipMemcpyHostToDevice, c.dp_stream));
-            pb[p].S.aligns = g_dp.aligns.as<LzDpAlign>() + oa; pb[p].S.segs = g_dp.segs.as<LzDpSeg>() + os;
-            pb[p].S.obi = g_dp.obi.as<s32>() + oa; pb[p].S.oed = g_dp.oed.as<s32>() + oa; pb[p].S.n_aligns = (s32)a;
             pb[p].qdp = items[p].qdp; pb[p].qlen = items[p].qlen; pb[p].tdp = items[p].tdp; pb[p].tlen = items[p].tlen;
-            oa += a; os += g;
             for (LzDpJob J : *items[p].jobs) { J.problem = (u32)p; jobs.push_back(J); }
         }
-        bounds = na != 0;
+        cur_items = &items;
+        // rows a job's pieces are worked out for at first: well past what its DP is expected to sweep (est_rows: the host's guess from
+        // the deferred anchors around it; rows = 1.2 x est_rows at the median, 2.2 x at the 90th percentile), never past its last row
+        horizon.resize(jobs.size());
+        static const u32 first_h = []() { const char* e = getenv("LZGPU_DP_HORIZON"); return (u32)(e ? atoi(e) : 0); }();       // tests: a short one
+        for (size_t k = 0; k < jobs.size(); k++) horizon[k] = std::min<u32>(jobs[k].M, first_h ? first_h : std::max<u32>(4u * jobs[k].est_rows + 4096u, 16384u));
         LZ_HIP(hipMemcpyAsync(g_dp.problems.p, pb.data(), pb.size() * sizeof(LzDpProblem), hipMemcpyHostToDevice, c.dp_stream));
         problems_dev = g_dp.problems.as<LzDpProblem>();
         std::vector<LzDpResult> res(jobs.size());
@@ -445,7 +464,7 @@ struct HipDpExec : LzDpExecutor {
             // keep the arenas within a sane budget: at most ~48 GiB of traceback per launch
             const u64 per = (u64)slot + (u64)(slot / 16 + 64) * 4 + (u64)(slot / 32 + 64) * 4;
             u64 max_jobs = (48ull << 30) / per; if (max_jobs < 1) max_jobs = 1;
-            std::vector<u32> retry, retry_wide;
+            std::vector<u32> retry, retry_wide, again, again_wide;       // in a larger slot / with pieces up to a farther horizon
             // the LDS-ring kernel first; what it finds too wide joins the HBM-ring launch of the same pass
             for (int pass = 0; pass < 2; pass++) {
                 const bool wide = pass == 1;
@@ -473,17 +492,20 @@ struct HipDpExec : LzDpExecutor {
                         const u32 stt = res[id].status;
                         if (stt == LZ_DP_OK) good.push_back(id);
                         else if (stt == LZ_DP_TB_SLOT || stt == LZ_DP_ROW_SLOT || stt == LZ_DP_OPS_SLOT) (wide ? retry_wide : retry).push_back(id);
+                        else if (stt == LZ_DP_PIECE_SLOT) { horizon[id] = horizon[id] < (1u << 27) ? horizon[id] * 8u : 0xFFFFFFF0u; piece_reruns++; (wide ? again_wide : again).push_back(id); }
                         else if (stt == LZ_DP_TOO_WIDE && !wide) wide_ids.push_back(id);
-                        else return LZGPU_NH_UNSUPPORTED;          // band wider than the HBM ring / too many active segments
+                        else return LZGPU_NH_UNSUPPORTED;          // band wider than the HBM ring
                     }
                     if ((rc = fetch_ops(jobs, good, res, ops))) return rc;
                 }
             }
             const u64 max_slot = std::max<u64>(P.tb_len, 1u << 20) * 2;
-            if ((!retry.empty() || !retry_wide.empty()) && !first_try && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
+            const bool slot_retry = !retry.empty() || !retry_wide.empty();
+            if (slot_retry && !first_try && slot >= max_slot) return LZGPU_NH_UNSUPPORTED;   // pathological: > slot/16 rows
+            retry.insert(retry.end(), again.begin(), again.end()); retry_wide.insert(retry_wide.end(), again_wide.begin(), again_wide.end());
             ids.swap(retry); wide_ids.swap(retry_wide);
             if (first_try) first_try = false;                      // (what overflowed its estimated slot: the uniform slot next)
-            else slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
+            else if (slot_retry) slot = (u32)std::min<u64>((u64)slot * 8, max_slot);
         }
         // ---- results back to their problems
         size_t o = 0;

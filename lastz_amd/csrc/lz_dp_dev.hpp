@@ -50,42 +50,49 @@
 #ifndef LZ_DP_STAMP_PERIOD
 #define LZ_DP_STAMP_PERIOD 65535        // rows after which the 16-bit mask stamps of the LDS ring start over (tests: a small period)
 #endif
-#define LZ_DP_ACT_LDS 16              // active segments kept in LDS (the rest in the job's HBM slot: LDS bytes per DP decide how many DPs share a CU)
-#define LZ_DP_MAXACT  4096            // active segments of earlier alignments crossing the sweep row
 #define LZ_DP_NEGINF  ((s32)-1932735283)      // negInfinity, src/dna_utilities.h:138
 
 enum { LZ_DIAG_SEG = 0, LZ_HORZ_SEG = 1, LZ_VERT_SEG = 2 };
 enum { LZ_C_FROM_C = 0, LZ_C_FROM_I = 1, LZ_C_FROM_D = 2, LZ_I_EXT = 4, LZ_D_EXT = 8 };
-enum { LZ_DP_OK = 0, LZ_DP_TOO_WIDE = 1, LZ_DP_TB_SLOT = 2, LZ_DP_ROW_SLOT = 3, LZ_DP_OPS_SLOT = 4, LZ_DP_ACT_SLOT = 5 };
+enum { LZ_DP_OK = 0, LZ_DP_TOO_WIDE = 1, LZ_DP_TB_SLOT = 2, LZ_DP_ROW_SLOT = 3, LZ_DP_OPS_SLOT = 4, LZ_DP_PIECE_SLOT = 5 };   // PIECE_SLOT: the sweep passed the job's piece horizon
 
 struct LzDpSeg   { u32 b1, b2, e1, e2; s32 type; };
-struct LzDpAlign {                      // galign, src/gapped_extend.c:222-250 (indices instead of pointers, -1 = NULL)
+struct LzDpAlign {                      // galign, src/gapped_extend.c:222-250 (indices instead of pointers, -1 = NULL); host side (LzHostSnapshot)
     u32 pos1, pos2, end1, end2;
     s32 first_seg, last_seg;            // this alignment's segments are segs[first_seg..last_seg]
     s32 left_align1, right_align1, left_align2, right_align2;
     s32 left_seg1, right_seg1, left_seg2, right_seg2;
 };
-struct LzDpSnapshot {                   // the bounding alignments a batch of DPs is run against
-    const LzDpAlign* aligns; const LzDpSeg* segs;
-    const s32* obi; const s32* oed; s32 n_aligns;     // obi: by increasing start; oed: by decreasing end
-};
+
+// How earlier alignments reach a one-sided DP (round 5).  The reference follows them while it sweeps: the bounding segments left and
+// right of the anchor, row by row (update_LR_bounds, src/gapped_extend.c:4588), and a list of the segments that cross the sweep row,
+// whose cells it masks (update_active_segs, :4885).  Both are functions of the job and of the alignments committed before it -- not of
+// anything the sweep computes -- so the host works them out once per job (lz_gapped_host.cpp: lzh_dp_pieces) as PIECES of rows:
+//   bound pieces   rows r0..r1: the bound is x0 + (row - r0) * (fl & 1); consecutive pieces are contiguous in rows; when the list ends
+//                  the bound is gone (the reference's left_seg / right_seg == NULL)
+//   mask pieces    rows r0..r1: the cells x .. x + (fl >> 1) with x = x0 + (row - r0) * (fl & 1) are masked (a diagonal or vertical
+//                  segment: one cell per row; a horizontal one: a run of cells on one row); sorted by r0
+// and the kernel reads the next piece when a row passes the end of the current one: no pointer chasing through alignments and segments
+// on the device, no serial list update per row -- the row's mask cells are stamped by the lanes, one piece each.  Pieces are complete
+// for rows <= LzDpJob::horizon; a sweep that gets further stops with LZ_DP_PIECE_SLOT and is run again with a longer horizon.
+struct LzDpPiece { u32 r0, r1; s32 x0; u32 fl; };
 
 struct LzDpJob {
     u32 anchor1, anchor2; s32 reversed; u32 M, N;
-    s32 left_align, right_align, left_seg, right_seg;   // io->leftAlign.. (msp_left_right)
-    s32 list_start;                     // index into obi (forward: aboveList) / oed (reversed: belowList), -1 = none
+    s32 left_align, right_align, left_seg, right_seg;   // io->leftAlign.. (msp_left_right): host side, input of lzh_dp_pieces
+    s32 list_start;                     // index into obi (forward: aboveList) / oed (reversed: belowList), -1 = none: host side
     u64 tb_off; u32 tb_cap;             // traceback bytes slot
     u64 row_off; u32 row_cap;           // tbRow[] slot (u32 per row)
     u64 ops_off; u32 ops_cap;           // edit ops slot (u32 each, traceback order)
-    u64 act_off;                        // overflow slot of the active-segment list (LZ_DP_MAXACT - LZ_DP_ACT_LDS entries)
+    u64 pc_off;                         // the job's pieces in the launch's arena: n_lb left-bound pieces, n_rb right-bound pieces, n_mk mask pieces
+    u32 n_lb, n_rb, n_mk, horizon;
     u32 est_rows;                       // host-side guess of how many rows this DP will sweep (launch order only: longest first)
     u32 problem;                        // which LzDpProblem of the launch this DP belongs to (0 in a single-problem launch)
 };
 
 // One launch can hold the DPs of several independent problems (the two strands of a query, the tweener windows of a
-// strand: lzgpu_gapped_extend_batch): each has its own bounding alignments and its own query; a job's indices
-// (left_align, list_start, ...) are relative to its problem's snapshot.
-struct LzDpProblem { LzDpSnapshot S; const u8* tdp; const u8* qdp; u32 tlen, qlen; };
+// strand: lzgpu_gapped_extend_batch): each has its own query / window of the sequences.
+struct LzDpProblem { const u8* tdp; const u8* qdp; u32 tlen, qlen; };
 
 struct LzDpResult {
     s32 score; u32 end1, end2; u32 n_ops; u32 status; u32 truncated;
@@ -104,11 +111,10 @@ struct LzDpParams {                     // per batch
     s32 no_trim;                        // !trimToPeak: an end on the last row / column may be reported instead of the peak (:3747-3750, :3866)
     u32 tb_len;                         // the REFERENCE's traceback size (truncation rule, :3640-3661)
     u8* tb_arena; u32* row_arena; u32* ops_arena;
-    struct LzDpActive* act_arena;
+    const LzDpPiece* pc_arena;
 };
 
 struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
-struct LzDpActive { s32 align, seg; u32 x, last_row; s32 type; s32 filter; };
 
 // The sweep row is a ring indexed by column & (RING-1).  Two homes for it: arrays in the DP's LDS block (the
 // normal kernel), or a slot in HBM behind pointers (k_ydrop_wide: the rare bands wider than the LDS ring --
@@ -157,15 +163,15 @@ struct LzDpSharedBase {
     // behind a branch behind a read is an LDS round trip each, ~100 cycles for a wave that has its SIMD to itself)
     alignas(16) u32 row; u32 LY, ry_iter, cpl;
     s32 best; u32 trow_cur, done, extra;
-    u32 n_act, fill_n, fill_base, fill_trow;              // work for all lanes before the next row
+    u32 mk_lo, fill_n, fill_base, fill_trow;              // work for all lanes before the next row (mk_lo, mk_hi: the mask pieces in reach of the row)
     u32 stage_lo, stage_a; s32 fill_i; u32 b_hi;
+    u32 mk_hi, pad_[3];
     u8  aa[LZ_DP_LANES];                  // A (target) score classes of a block of 64 rows
     // per-wave partials of the cross-lane steps (GPU executor) and the row results (written by lane 0)
     LzDpGap wg[LZ_DP_WAVES]; s32 wc[LZ_DP_WAVES], wcmax[LZ_DP_WAVES]; u32 wfirst[LZ_DP_WAVES], wlast[LZ_DP_WAVES], wccol[LZ_DP_WAVES], whas[LZ_DP_WAVES];
     u32 r_first, r_last, r_ccol; s32 r_cmax;
     // traceback state
     u32 tb_row, tb_col, tb_prev, tb_nops, tb_run_op, tb_run_len, tb_done;
-    LzDpActive act[LZ_DP_ACT_LDS];        // the first active segments; the rest live in the job's HBM slot
 };
 template <class Ring> struct LzDpSharedT : LzDpSharedBase, Ring {};
 typedef LzDpSharedT<LzDpRingLds<LZ_DP_MAXW>> LzDpShared;
@@ -178,12 +184,13 @@ typedef LzDpSharedT<LzDpRingHbm> LzDpSharedWide;
 struct LzDpCtl {
     s32 L, R; u32 LY, RY, prevLY, row;
     s32 best; u32 end1, end2;
-    s32 left_align, right_align, left_seg, right_seg, list_pos;
-    u32 tb_used, n_act, done, status, truncated;
-    u32 next_act_row;                     // row at which aligns[order[list_pos]] becomes active
+    u32 tb_used, done, status, truncated;
     u32 b_hi;                             // columns < b_hi are staged in bb[]
     u32 max_row, min_col, max_col; u64 cells;
-    LzDpSeg lcur, rcur;                   // copies of segs[left_seg] / segs[right_seg]
+    // the bounds and the masks, from the job's pieces: the piece in force and its index (== the count: the bound is gone)
+    u32 lbi, rbi; LzDpPiece lb, rb;
+    u32 mk_lo, mk_hi;                     // mask pieces [mk_lo, mk_hi) may hold cells of the current row
+    u32 mk_lo_r1, mk_next_r0;             // last row of piece mk_lo; first row of piece mk_hi (the next to come into reach)
 };
 
 struct LzDpLane {                       // per-lane values carried between the steps of one row (registers on the GPU)
@@ -254,148 +261,14 @@ LZ_HD u32 lz_mul24(u32 a, u32 b) { return a * b; }
 #endif
 #define LZ_RING(c) ((c) & (SH::RING - 1))
 
-// next_sweep_seg / prev_sweep_seg, src/gapped_extend.c:4754-4850
-LZ_HD s32 lz_dp_next_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, s32& al, u32 row, u32 a1, u32 a2)
-{
-    seg = (seg < S.aligns[al].last_seg) ? seg + 1 : -1;
-    if (seg >= 0) {
-        if (S.segs[seg].type == LZ_HORZ_SEG) seg = (seg < S.aligns[al].last_seg) ? seg + 1 : -1;   // (the reference aborts on a trailing horizontal)
-        if (seg >= 0) return LZ_SDIFF(S.segs[seg].b2, a2);
-        return 0;
-    }
-    if (look_right) { seg = S.aligns[al].right_seg2; al = S.aligns[al].right_align2; }
-    else            { seg = S.aligns[al].left_seg2;  al = S.aligns[al].left_align2; }
-    if (seg < 0) return 0;
-    if (S.segs[seg].type == LZ_DIAG_SEG) return (s32)row + LZ_SDIFF(S.segs[seg].b2, a2) - LZ_SDIFF(S.segs[seg].b1, a1);
-    return LZ_SDIFF(S.segs[seg].b2, a2);
-}
-LZ_HD s32 lz_dp_prev_sweep_seg(const LzDpSnapshot& S, int look_right, s32& seg, s32& al, u32 row, u32 a1, u32 a2)
-{
-    seg = (seg > S.aligns[al].first_seg) ? seg - 1 : -1;
-    if (seg >= 0) {
-        if (S.segs[seg].type == LZ_HORZ_SEG) seg = (seg > S.aligns[al].first_seg) ? seg - 1 : -1;
-        if (seg >= 0) return LZ_SDIFF(a2, S.segs[seg].e2);
-        return 0;
-    }
-    if (look_right) { seg = S.aligns[al].right_seg1; al = S.aligns[al].right_align1; }
-    else            { seg = S.aligns[al].left_seg1;  al = S.aligns[al].left_align1; }
-    if (seg < 0) return 0;
-    if (S.segs[seg].type == LZ_DIAG_SEG) return (s32)row + LZ_SDIFF(a2, S.segs[seg].e2) - LZ_SDIFF(a1, S.segs[seg].e1);
-    return LZ_SDIFF(a2, S.segs[seg].e2);
-}
-
 LZ_HD u32 lz_dp_special_min(u32 ry, s32 r) { if (r <= 0) return 0; if ((u32)r < ry) return (u32)r; return ry; }
 
 // A value that lane-0 code keeps across rows must not stay "pending on a global load" in the eyes of the
 // compiler: a later use would then wait for vmcnt(0), i.e. for every traceback store still in flight,
 // on every row.  Passing it through X::uni right where it is loaded settles it there.
-template <class X> LZ_HD LzDpSeg lz_dp_uni_seg(X& x, const LzDpSeg& g)
-{ LzDpSeg r; r.b1 = x.uni(g.b1); r.b2 = x.uni(g.b2); r.e1 = x.uni(g.e1); r.e2 = x.uni(g.e2); r.type = x.uni(g.type); return r; }
-
-// update_LR_bounds, src/gapped_extend.c:4588-4700 (lane 0).  The bounding segments change every
-// few hundred rows but are consulted on every row: their fields are kept in LDS (c.lcur / c.rcur)
-// and re-read from HBM only when next/prev_sweep_seg moves to another segment.
-template <class X>
-LZ_HD void lz_dp_update_lr(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJob& J)
-{
-    s32 L = c.L, R = c.R; u32 LY = c.LY, RY = c.RY;
-    const u32 row = c.row, a1 = J.anchor1, a2 = J.anchor2;
-    if (!J.reversed) {
-        if (c.left_seg >= 0) {
-            if (c.lcur.e1 >= row + a1) { if (c.lcur.type == LZ_DIAG_SEG) L++; }
-            else { L = x.uni(lz_dp_next_sweep_seg(S, 0, c.left_seg, c.left_align, row, a1, a2)) + 1; c.left_seg = x.uni(c.left_seg); c.left_align = x.uni(c.left_align); if (c.left_seg >= 0) c.lcur = lz_dp_uni_seg(x, S.segs[c.left_seg]); }
-        }
-        if (c.left_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
-        if (c.right_seg >= 0) {
-            if (c.rcur.e1 >= row + a1) { if (c.rcur.type == LZ_DIAG_SEG) R++; }
-            else { R = x.uni(lz_dp_next_sweep_seg(S, 1, c.right_seg, c.right_align, row, a1, a2)) - 1; c.right_seg = x.uni(c.right_seg); c.right_align = x.uni(c.right_align); if (c.right_seg >= 0) c.rcur = lz_dp_uni_seg(x, S.segs[c.right_seg]); }
-        }
-        if (c.right_seg >= 0) RY = lz_dp_special_min(RY, R);
-    } else {
-        if (c.right_seg >= 0) {
-            if (c.rcur.b1 <= a1 - row) { if (c.rcur.type == LZ_DIAG_SEG) L++; }
-            else { L = x.uni(lz_dp_prev_sweep_seg(S, 1, c.right_seg, c.right_align, row, a1, a2)) + 1; c.right_seg = x.uni(c.right_seg); c.right_align = x.uni(c.right_align); if (c.right_seg >= 0) c.rcur = lz_dp_uni_seg(x, S.segs[c.right_seg]); }
-        }
-        if (c.right_seg >= 0) LY = (u32)(((s32)LY > L) ? (s32)LY : L);
-        if (c.left_seg >= 0) {
-            if (c.lcur.b1 <= a1 - row) { if (c.lcur.type == LZ_DIAG_SEG) R++; }
-            else { R = x.uni(lz_dp_prev_sweep_seg(S, 0, c.left_seg, c.left_align, row, a1, a2)) - 1; c.left_seg = x.uni(c.left_seg); c.left_align = x.uni(c.left_align); if (c.left_seg >= 0) c.lcur = lz_dp_uni_seg(x, S.segs[c.left_seg]); }
-        }
-        if (c.left_seg >= 0) RY = lz_dp_special_min(RY, R);
-    }
-    c.L = L; c.R = R; c.LY = LY; c.RY = RY;
-}
-
-// build_active_seg, src/gapped_extend.c:4992-5035: only cells inside [LY,RY] are stamped (that
-// also keeps the ring free of aliases: RY - LY < MAXW)
-template <class SH> LZ_HD void lz_dp_stamp(SH& sh, const LzDpCtl& c, u32 x, u32 row) { if (x >= c.LY && x <= c.RY) sh.mk[LZ_RING(x)] = (typename SH::stamp_t)SH::stamp(row); }
-template <class SH> LZ_HD void lz_dp_build_active(const LzDpSnapshot& S, SH& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive& act)
-{
-    const LzDpSeg& sg = S.segs[act.seg];
-    act.type = sg.type;
-    if (!J.reversed) { act.x = sg.b2 - J.anchor2; act.last_row = sg.e1 - J.anchor1; }
-    else             { act.x = J.anchor2 - sg.e2; act.last_row = J.anchor1 - sg.b1; }
-    if (act.type != LZ_HORZ_SEG) lz_dp_stamp(sh, c, act.x, c.row);
-    else {
-        u32 horz_end = (!J.reversed) ? sg.e2 - J.anchor2 : J.anchor2 - sg.b2;
-        u32 i_min = c.LY > act.x ? c.LY : act.x;
-        u32 i_max = c.RY < horz_end ? c.RY : horz_end;
-        if (i_min <= i_max) for (u32 i = i_min; i <= i_max; i++) sh.mk[LZ_RING(i)] = (typename SH::stamp_t)SH::stamp(c.row);
-    }
-}
-
-// row at which the alignment at the head of the above/below list reaches the sweep (or none)
-template <class X>
-LZ_HD void lz_dp_peek_list(X& x, const LzDpSnapshot& S, LzDpCtl& c, const LzDpJob& J)
-{
-    if (c.list_pos < 0 || c.list_pos >= S.n_aligns) { c.list_pos = -1; c.next_act_row = 0xFFFFFFFFu; return; }
-    const s32* order = J.reversed ? S.oed : S.obi;
-    const LzDpAlign& al = S.aligns[order[c.list_pos]];
-    c.next_act_row = x.uni(J.reversed ? (J.anchor1 - al.end1) : (al.pos1 - J.anchor1));
-}
-
-LZ_HD LzDpActive& lz_dp_act(LzDpSharedBase& sh, LzDpActive* spill, u32 k) { return k < LZ_DP_ACT_LDS ? sh.act[k] : spill[k - LZ_DP_ACT_LDS]; }
-
-// update_active_segs, src/gapped_extend.c:4885-4965 (lane 0)
-template <class X, class SH>
-LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, SH& sh, LzDpCtl& c, const LzDpJob& J, LzDpActive* spill)
-{
-    const u32 row = c.row;
-    for (u32 k = 0; k < c.n_act; k++) {
-        LzDpActive& act = lz_dp_act(sh, spill, k);
-        if (act.last_row >= row) {
-            if (act.type == LZ_DIAG_SEG) act.x++;
-            lz_dp_stamp(sh, c, act.x, row);
-        } else {
-            const LzDpAlign& al = S.aligns[act.align];
-            s32 nx = J.reversed ? ((act.seg > al.first_seg) ? act.seg - 1 : -1) : ((act.seg < al.last_seg) ? act.seg + 1 : -1);
-            if (nx >= 0) {
-                act.seg = nx;
-                lz_dp_build_active(S, sh, c, J, act);
-                if (act.type == LZ_HORZ_SEG) {
-                    act.seg = J.reversed ? act.seg - 1 : act.seg + 1;     // (a horizontal piece is never terminal)
-                    lz_dp_build_active(S, sh, c, J, act);
-                }
-            } else act.filter = 1;
-        }
-    }
-    // alignments the sweep row now reaches (the reference prepends; order within the list is
-    // immaterial).  The row at which the head of the list starts is cached (c.next_act_row).
-    while (c.list_pos >= 0 && c.next_act_row == row) {
-        const s32* order = J.reversed ? S.oed : S.obi;
-        const LzDpAlign& al = S.aligns[order[c.list_pos]];
-        if (c.n_act >= LZ_DP_MAXACT) { c.status = LZ_DP_ACT_SLOT; c.done = 1; return; }
-        LzDpActive& act = lz_dp_act(sh, spill, c.n_act++);
-        act.filter = 0; act.align = order[c.list_pos];
-        act.seg = J.reversed ? al.last_seg : al.first_seg;
-        lz_dp_build_active(S, sh, c, J, act);
-        c.list_pos++;
-        lz_dp_peek_list(x, S, c, J);
-    }
-    u32 w = 0;                                                 // filter_active_segs(&active, 0)
-    for (u32 k = 0; k < c.n_act; k++) if (lz_dp_act(sh, spill, k).filter == 0) { if (w != k) lz_dp_act(sh, spill, w) = lz_dp_act(sh, spill, k); w++; }
-    c.n_act = w;
-}
+template <class X> LZ_HD LzDpPiece lz_dp_uni_piece(X& x, const LzDpPiece& g)
+{ LzDpPiece r; r.r0 = x.uni(g.r0); r.r1 = x.uni(g.r1); r.x0 = x.uni(g.x0); r.fl = x.uni(g.fl); return r; }
+LZ_HD s32 lz_dp_piece_at(const LzDpPiece& p, u32 row) { return p.x0 + ((p.fl & 1u) ? (s32)(row - p.r0) : 0); }
 
 // ------------------------------------------------------------------------------------------------
 // NOTRIM: !trimToPeak, a compile-time switch (its four per-lane values cost the default kernel nine spilled registers
@@ -405,7 +278,7 @@ LZ_HD void lz_dp_update_active(X& x, const LzDpSnapshot& S, SH& sh, LzDpCtl& c, 
 // drop out at compile time (7.2 k -> 6.7 k cycles per row with the routines skipped by a run-time test alone).
 // REPLICATE (only without BOUNDS): see REPL below.
 template <bool NOTRIM, bool BOUNDS, bool REPLICATE, class X, class SH>
-LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, const LzDpJob& J,
+LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
 {
     const s32 gapE = P.gap_e, gapOE = P.gap_oe, Y = P.ydrop;
@@ -413,6 +286,9 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     u8*  tb   = P.tb_arena  + J.tb_off;
     u32* trow = P.row_arena + J.row_off;
     u32* ops  = P.ops_arena + J.ops_off;
+    const LzDpPiece* const pc_lb = P.pc_arena + J.pc_off;        // the job's pieces (BOUNDS): left bound, right bound, masks
+    const LzDpPiece* const pc_rb = pc_lb + J.n_lb;
+    const LzDpPiece* const pc_mk = pc_rb + J.n_rb;
 
     if (N == 0 || M == 0) {                                     // :3466-3467
         x.phase([&](int lane, LzDpLane&) {
@@ -436,20 +312,14 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
     LzDpCtl ct;                                                 // lane 0's (REPL: every wave's)
     // ---- set-up + row 0 (:3500-3605)
     auto setup = [&]() {
-        s32 L = 0, R = (s32)N + 1;
-        if (J.left_seg >= 0)  { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.left_seg]);  L = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) L -= LZ_SDIFF(g.b1, J.anchor1); }
-        if (J.right_seg >= 0) { const LzDpSeg g = lz_dp_uni_seg(x, S.segs[J.right_seg]); R = LZ_SDIFF(g.b2, J.anchor2); if (g.type == LZ_DIAG_SEG) R -= LZ_SDIFF(g.b1, J.anchor1); }
-        if (J.reversed) {                                       // note (14), :3536-3541
-            if (J.left_seg < 0 && J.right_seg >= 0)       { L = -R + 1; R = (s32)N + 1; }
-            else if (J.left_seg >= 0 && J.right_seg < 0)  { R = -L - 1; L = 0; }
-            else if (J.left_seg >= 0 && J.right_seg >= 0) { s32 t = -L - 1; L = -R + 1; R = t; }
+        ct.L = 0; ct.R = (s32)N + 1;                           // (row 0 is not bounded: the first bound is read for row 1)
+        ct.lbi = ct.rbi = 0; ct.mk_lo = ct.mk_hi = 0; ct.mk_lo_r1 = 0; ct.mk_next_r0 = 0xFFFFFFFFu;
+        ct.lb.r0 = ct.lb.r1 = 0; ct.lb.x0 = 0; ct.lb.fl = 0; ct.rb = ct.lb;
+        if (BOUNDS) {
+            if (J.n_lb) ct.lb = lz_dp_uni_piece(x, pc_lb[0]);
+            if (J.n_rb) ct.rb = lz_dp_uni_piece(x, pc_rb[0]);
+            if (J.n_mk) { ct.mk_next_r0 = x.uni(pc_mk[0].r0); ct.mk_lo_r1 = x.uni(pc_mk[0].r1); }
         }
-        ct.L = L; ct.R = R;
-        ct.left_align = J.left_align; ct.right_align = J.right_align; ct.left_seg = J.left_seg; ct.right_seg = J.right_seg;
-        if (ct.left_seg >= 0) ct.lcur = lz_dp_uni_seg(x, S.segs[ct.left_seg]);
-        if (ct.right_seg >= 0) ct.rcur = lz_dp_uni_seg(x, S.segs[ct.right_seg]);
-        ct.list_pos = J.list_start; ct.n_act = 0;
-        lz_dp_peek_list(x, S, ct, J);
         ct.done = 0; ct.status = LZ_DP_OK; ct.truncated = 0;
         ct.best = 0; ct.end1 = ct.end2 = 0; ct.row = 0; ct.cells = 0;
         ct.max_row = 0; ct.min_col = 0; ct.max_col = 0;
@@ -463,7 +333,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
         ct.b_hi = 1; sh.trow_cur = 0;
         while (ct.RY + 2 > ct.b_hi) ct.b_hi += LZ_DP_LANES;     // columns [1, b_hi) are staged by the next phase
         ct.max_col = n0 ? n0 - 1 : 0;
-        sh.done = ct.done; sh.b_hi = ct.b_hi; sh.ry_iter = n0; sh.row = 0; sh.LY = 0; sh.best = 0; sh.n_act = 0; sh.extra = 0;
+        sh.done = ct.done; sh.b_hi = ct.b_hi; sh.ry_iter = n0; sh.row = 0; sh.LY = 0; sh.best = 0; sh.mk_lo = sh.mk_hi = 0; sh.extra = 0;
     };
     if (REPL) x.every_wave(setup); else x.leader(setup);
     if (!sh.done) {
@@ -516,7 +386,10 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
                 ct.LY = first;
                 if (LY0 < ct.min_col) ct.min_col = LY0;
                 ct.max_row = row;
-                const s32 NN = (ct.right_seg >= 0 && ct.R > 0) ? ct.R - 1 : (s32)N;
+                // (:3787 asks for the RIGHT neighbour's segment whichever way the sweep goes; in a backward sweep that segment drives the
+                // left bound -- lzh_dp_pieces -- so "it is still there" is read off the left bound's pieces then)
+                const bool right_seg_alive = BOUNDS && (J.reversed ? ct.lbi < J.n_lb : ct.rbi < J.n_rb);
+                const s32 NN = (right_seg_alive && ct.R > 0) ? ct.R - 1 : (s32)N;
                 u32 RY = RYi, np = 0;
                 if (RY > last + 1) RY = last + 1;
                 else {
@@ -550,13 +423,25 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             if (ct.row >= M) { ct.done = 1; return; }
             ct.row++;
             ct.prevLY = ct.LY;
-            if (BOUNDS) lz_dp_update_lr(x, S, ct, J);
+            if (BOUNDS) {
+                if (ct.row > J.horizon) { ct.status = LZ_DP_PIECE_SLOT; ct.done = 1; return; }      // the pieces end here: run again with more of them
+                // the row's bounds (update_LR_bounds, :4588-4700): the piece in force, or the next one when the row has passed its end
+                // (a bound that ends leaves 0 + 1 / 0 - 1 behind, as the reference's last look for a next segment does: R is still read by
+                // the row end of a backward sweep, :3787, after the segment that drove it is gone)
+                while (ct.lbi < J.n_lb && ct.row > ct.lb.r1) { ct.lbi++; if (ct.lbi < J.n_lb) ct.lb = lz_dp_uni_piece(x, pc_lb[ct.lbi]); else ct.L = 1; }
+                if (ct.lbi < J.n_lb) { ct.L = lz_dp_piece_at(ct.lb, ct.row); ct.LY = (u32)(((s32)ct.LY > ct.L) ? (s32)ct.LY : ct.L); }
+                while (ct.rbi < J.n_rb && ct.row > ct.rb.r1) { ct.rbi++; if (ct.rbi < J.n_rb) ct.rb = lz_dp_uni_piece(x, pc_rb[ct.rbi]); else ct.R = -1; }
+                if (ct.rbi < J.n_rb) { ct.R = lz_dp_piece_at(ct.rb, ct.row); ct.RY = lz_dp_special_min(ct.RY, ct.R); }
+            }
             q3 = LZ_PHASE_CLOCK();
             if (BOUNDS && SH::STAMP_WRAPS && ct.row > 1 && SH::stamp(ct.row) == 1u)   // the 16-bit stamps start over: none of the old ones may survive
                 for (u32 k = 0; k < SH::RING; k++) sh.mk[k] = 0;
-            if (BOUNDS) lz_dp_update_active(x, S, sh, ct, J, P.act_arena + J.act_off);
+            if (BOUNDS) {
+                // the mask pieces in reach of the row (update_active_segs, :4885-4965): those that have begun, from the first that has not ended
+                while (ct.mk_hi < J.n_mk && ct.mk_next_r0 <= ct.row) { ct.mk_hi++; if (ct.mk_hi < J.n_mk) ct.mk_next_r0 = x.uni(pc_mk[ct.mk_hi].r0); }
+                while (ct.mk_lo < ct.mk_hi && ct.mk_lo_r1 < ct.row) { ct.mk_lo++; if (ct.mk_lo < J.n_mk) ct.mk_lo_r1 = x.uni(pc_mk[ct.mk_lo].r1); }
+            }
             q4 = LZ_PHASE_CLOCK();
-            if (ct.done) return;
             if (ct.RY < ct.LY) ct.RY = ct.LY;                   // note 11
             const u32 width = ct.RY - ct.LY;
             const s32 tb_needed = (s32)width + P.ydrop_tail;
@@ -572,7 +457,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             if (!REPL) {
                 sh.row = ct.row; sh.LY = ct.LY; sh.ry_iter = p_ry_iter; sh.cpl = p_cpl;
                 sh.best = ct.best; sh.trow_cur = p_trow_cur; sh.done = ct.done; sh.extra = p_extra;
-                sh.n_act = ct.n_act; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
+                sh.mk_lo = ct.mk_lo; sh.mk_hi = ct.mk_hi; sh.fill_n = p_fill_n; sh.fill_base = p_fill_base; sh.fill_trow = p_fill_trow;
                 sh.stage_lo = p_stage_lo; sh.stage_a = p_stage_a; sh.fill_i = p_fill_i; sh.b_hi = ct.b_hi;
             }
             const u64 q5 = LZ_PHASE_CLOCK();
@@ -580,7 +465,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             tl[0] += q1 - q0; tl[1] += q2 - q1; tl[2] += q3 - q2; tl[3] += q4 - q3; tl[4] += q5 - q4;
         };
         if (REPL) x.every_wave(control); else x.leader(control);
-        u32 e_on, n_act_now = 0;
+        u32 e_on, mk_lo_now = 0, mk_hi_now = 0;
         if (REPL) {
             finished = x.uni(ct.done) != 0u; e_on = p_extra;
             row = x.uni(ct.row); LY0 = x.uni(ct.LY); RYi = x.uni(p_ry_iter); cpl = x.uni(p_cpl); best0 = x.uni(ct.best); trow_cur = x.uni(p_trow_cur);
@@ -588,7 +473,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             // the published words of every row, read together (two 128-bit reads and one wait), then the branches
             const u32 v_row = sh.row, v_ly = sh.LY, v_ry = sh.ry_iter, v_cpl = sh.cpl, v_trow = sh.trow_cur, v_done = sh.done, v_extra = sh.extra;
             const s32 v_best = sh.best;
-            if (BOUNDS) n_act_now = sh.n_act;
+            if (BOUNDS) { mk_lo_now = x.uni((u32)sh.mk_lo); mk_hi_now = x.uni((u32)sh.mk_hi); }
             finished = x.uni(v_done) != 0u; e_on = x.uni(v_extra);
             row = x.uni(v_row); LY0 = x.uni(v_ly); RYi = x.uni(v_ry); cpl = x.uni(v_cpl); best0 = x.uni(v_best); trow_cur = x.uni(v_trow);
         }
@@ -613,8 +498,24 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpSnapshot& S, const LzDpParams& P, c
             });
         }
         swept = true;
-        const bool any_active = BOUNDS && (REPL ? ct.n_act : n_act_now) != 0;
+        const bool any_active = BOUNDS && mk_hi_now > mk_lo_now;
         const u32 row_stamp = SH::stamp(row);
+        // The row's masked cells, stamped by the lanes: lane l takes pieces mk_lo + l, mk_lo + l + LANES, ... of those in reach; a piece
+        // that covers the row masks x .. x + extra, clipped to the band (that also keeps the ring free of aliases: RY - LY < RING).
+        // (build_active_seg, :4992-5035; the reference walks a linked list of segments here, one at a time.)
+        if (any_active) {
+            x.phase([&](int lane, LzDpLane&) {
+                for (u32 k = mk_lo_now + (u32)lane; k < mk_hi_now; k += LZ_DP_LANES) {
+                    const LzDpPiece pc = pc_mk[k];
+                    if (row < pc.r0 || row > pc.r1) continue;
+                    const s32 xs = lz_dp_piece_at(pc, row);
+                    if (xs < 0) continue;                                  // (the reference keeps the column unsigned: left of column 0 it is outside every band)
+                    const u32 x0 = (u32)xs, x1 = x0 + (pc.fl >> 1);
+                    const u32 lo = x0 > LY0 ? x0 : LY0, hi = x1 < RYi ? x1 : RYi;
+                    for (u32 c = lo; c <= hi; c++) sh.mk[LZ_RING(c)] = (typename SH::stamp_t)row_stamp;
+                }
+            });
+        }
         // the row's A class: fetched during the previous row (arow_next) unless this row opens a freshly staged block of aa[]
         const u32 aidx = (row - 1) & (LZ_DP_LANES - 1);
         const u32 arow = aidx == 0 ? x.uni((u32)sh.aa[0]) : arow_next;

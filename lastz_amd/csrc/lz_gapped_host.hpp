@@ -51,6 +51,11 @@ struct LzGappedParams {
 
 struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };
 
+// The bounds and the masked cells a job will meet, as pieces of rows complete up to `horizon` (lz_dp_pieces.cpp; LzDpPiece in
+// lz_dp_dev.hpp).  complete: no row beyond the horizon would add a piece (then the pieces hold for any number of rows).
+struct LzDpPieces { std::vector<LzDpPiece> lb, rb, mk; bool complete = true; };
+void lzh_dp_pieces(const LzHostSnapshot& S, const LzDpJob& J, u32 horizon, LzDpPieces& out);
+
 void lzh_reduce_to_points(const u8* t, const u8* q, const s32* sub, lz_segment* segs, u32 n);
 
 int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* anchors, u32 n_anchors,

@@ -63,34 +63,44 @@ struct EmulExec : LzDpExecutor {
     u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
     s32 gap_e, gap_oe, ydrop; u32 tb_len; s32 no_trim = 0;
     u32 tb_slot;                        // first-try slot size (tests shrink it to exercise the retry)
-    u64 retries = 0, wide_runs = 0;
+    u64 retries = 0, wide_runs = 0, piece_reruns = 0;
     int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
             std::vector<std::vector<u32>>& ops) override
     {
-        LzDpSnapshot S; S.aligns = snap.aligns.data(); S.segs = snap.segs.data();
-        S.obi = snap.obi.data(); S.oed = snap.oed.data(); S.n_aligns = (s32)snap.aligns.size();
         static LzDpShared sh;
+        const bool bounded = !snap.aligns.empty();
+        static const u32 first_horizon = []() { const char* e = getenv("EMUL_DP_HORIZON"); return (u32)(e ? atoi(e) : 0); }();   // tests: a short one, to run into the re-run
         for (size_t k = 0; k < jobs.size(); k++) {
             u32 slot = tb_slot;
+            u32 horizon = first_horizon ? first_horizon : jobs[k].M;
             for (;;) {
                 std::vector<u8> tb(slot); std::vector<u32> rows(slot / 16 + 16), opbuf(slot / 4 + 16);
                 LzDpParams P; P.tdp = tdp.data() + LZ_SEQ_PAD; P.tlen = tlen; P.qdp = qdp.data() + LZ_SEQ_PAD; P.qlen = qlen;
                 P.gap_e = gap_e; P.gap_oe = gap_oe; P.ydrop = ydrop; P.ydrop_tail = ydrop / gap_e + 6; P.tb_len = tb_len; P.no_trim = no_trim;
-                std::vector<LzDpActive> spill(LZ_DP_MAXACT - LZ_DP_ACT_LDS);
-                P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data(); P.act_arena = spill.data();
+                // the job's pieces, as the product's executor lays them out: left bound, right bound, masks
+                LzDpPieces pcs; lzh_dp_pieces(snap, jobs[k], horizon, pcs);
+                std::vector<LzDpPiece> arena(pcs.lb); arena.insert(arena.end(), pcs.rb.begin(), pcs.rb.end()); arena.insert(arena.end(), pcs.mk.begin(), pcs.mk.end());
+                arena.push_back(LzDpPiece{ 0, 0, 0, 0 });
+                P.tb_arena = tb.data(); P.row_arena = rows.data(); P.ops_arena = opbuf.data(); P.pc_arena = arena.data();
                 LzDpJob& J = jobs[k];
-                J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size(); J.act_off = 0;
+                J.tb_off = 0; J.tb_cap = slot; J.row_off = 0; J.row_cap = (u32)rows.size(); J.ops_off = 0; J.ops_cap = (u32)opbuf.size();
+                J.pc_off = 0; J.n_lb = (u32)pcs.lb.size(); J.n_rb = (u32)pcs.rb.size(); J.n_mk = (u32)pcs.mk.size();
+                J.horizon = pcs.complete ? 0xFFFFFFFFu : horizon;
                 CpuPhases x;
-                if (S.n_aligns) { if (no_trim) lz_dp_run<true, true, false>(x, sh, S, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(x, sh, S, P, J, tab, &res[k]); }
-                else             { if (no_trim) (k & 1 ? lz_dp_run<true, false, true, CpuPhases, LzDpShared> : lz_dp_run<true, false, false, CpuPhases, LzDpShared>)(x, sh, S, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, false, true, CpuPhases, LzDpShared> : lz_dp_run<false, false, false, CpuPhases, LzDpShared>)(x, sh, S, P, J, tab, &res[k]); }
+                if (bounded) { if (no_trim) lz_dp_run<true, true, false>(x, sh, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(x, sh, P, J, tab, &res[k]); }
+                else         { if (no_trim) (k & 1 ? lz_dp_run<true, false, true, CpuPhases, LzDpShared> : lz_dp_run<true, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, false, true, CpuPhases, LzDpShared> : lz_dp_run<false, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); }
                 if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
                     static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
                     static LzDpSharedWide shw;
                     shw.bind(ring.data());
                     CpuPhases xw;
-                    if (S.n_aligns) { if (no_trim) lz_dp_run<true, true, false>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(xw, shw, S, P, J, tab, &res[k]); }
-                    else             { if (no_trim) lz_dp_run<true, false, true>(xw, shw, S, P, J, tab, &res[k]); else lz_dp_run<false, false, true>(xw, shw, S, P, J, tab, &res[k]); }
+                    if (bounded) { if (no_trim) lz_dp_run<true, true, false>(xw, shw, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(xw, shw, P, J, tab, &res[k]); }
+                    else         { if (no_trim) lz_dp_run<true, false, true>(xw, shw, P, J, tab, &res[k]); else lz_dp_run<false, false, true>(xw, shw, P, J, tab, &res[k]); }
                     wide_runs++;
+                }
+                if (res[k].status == LZ_DP_PIECE_SLOT) {            // the sweep passed the pieces' horizon: again with more of them
+                    horizon = horizon < (1u << 28) ? horizon * 4 : 0xFFFFFFF0u; piece_reruns++;
+                    continue;
                 }
                 if (res[k].status == LZ_DP_TB_SLOT || res[k].status == LZ_DP_ROW_SLOT || res[k].status == LZ_DP_OPS_SLOT) {
                     if (slot >= tb_len) return LZGPU_ERR_STATE;
@@ -112,7 +122,8 @@ static void dp_codes(const u8* seq, u32 len, const u8 cls[256], std::vector<u8>&
     for (u32 i = 0; i < len; i++) out[LZ_SEQ_PAD + i] = cls[seq[i]] & 31;
 }
 
-static LzGappedStats g_stats; static u64 g_retries, g_wide;
+static LzGappedStats g_stats; static u64 g_retries, g_wide, g_piece_reruns;
+extern "C" u64 emul_gapped_piece_reruns(void) { return g_piece_reruns; }        // DPs run again because the sweep passed their pieces' horizon (cumulative)
 extern "C" void emul_gapped_stats(u64* out) { out[0] = g_stats.anchors; out[1] = g_stats.anchors_extended; out[2] = g_stats.dp_runs;
     out[3] = g_stats.dp_cells; out[4] = g_stats.rounds; out[5] = g_stats.reruns; out[6] = g_retries; out[7] = g_wide; }
 
@@ -136,7 +147,7 @@ extern "C" int emul_gapped_extend(const u8* t, u32 tlen, const u8* q, u32 qlen, 
     if (reduce) lzh_reduce_to_points(t, q, sub, anchors, n_anchors);
     std::vector<lz_align> al; std::vector<u32> op;
     rc = lzh_gapped_extend(G, ex, anchors, n_anchors, al, op, g_stats);
-    g_retries = ex.retries; g_wide = ex.wide_runs;
+    g_retries = ex.retries; g_wide = ex.wide_runs; g_piece_reruns += ex.piece_reruns;
     if (rc) return rc;
     *out = (lz_align*)malloc((al.size() ? al.size() : 1) * sizeof(lz_align));
     *ops = (u32*)malloc((op.size() ? op.size() : 1) * 4);

@@ -16,14 +16,15 @@ EMUL_DIR = os.path.join(H.ROOT, "tests", "emul")
 CS = os.path.join(H.ROOT, "lastz_amd", "csrc")
 
 
+ARGTYPES = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32,
+            C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+
+
 @pytest.fixture(scope="module")
 def L():
     so = H.build_emul()
     lib = C.CDLL(so)
-    lib.emul_gapped_extend.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int32, C.c_int32,
-                                       C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32,
-                                       C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
-                                       C.POINTER(C.c_uint64)]
+    lib.emul_gapped_extend.argtypes = ARGTYPES
     return lib
 
 
@@ -97,6 +98,28 @@ def test_helper_threads_of_the_commit_pass():
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.join(H.ROOT, "tests", "test_emul_gapped.py"),
                         "-k", "golden_cases or obstacle_course"], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=1500)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_a_sweep_that_passes_its_piece_horizon_is_run_again():
+    """Round 5: bounds and masked cells reach the DP as pieces of rows worked out on the host (lz_dp_pieces.cpp), complete up to a
+    horizon; a sweep that gets further stops (LZ_DP_PIECE_SLOT) and is run again with more pieces.  With a first horizon of 97 rows the
+    obstacle course (hundreds of alignments bounding and masking each other) takes that path in most of its DPs: same alignments,
+    scripts and cell counts as the oracle."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H, test_emul_gapped as T\n"
+            "lib = C.CDLL(H.build_emul()); lib.emul_gapped_extend.argtypes = T.ARGTYPES; lib.emul_gapped_piece_reruns.restype = C.c_uint64\n"
+            "t, q = H.load_case('adversarial')\n"
+            "st = T._check(lib, t[9000:14500], q[29500:34000])\n"
+            "t, q = H.load_case('synth_overlap')\n"
+            "T._check(lib, t, q)\n"
+            "n = lib.emul_gapped_piece_reruns()\n"
+            "assert n > 200, n\n"
+            "print('reruns', n)\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ); env["EMUL_DP_HORIZON"] = "97"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=1500)
+    assert p.returncode == 0 and "reruns" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_indexed_neighbour_search_equals_plain_walk(L):
