@@ -802,8 +802,10 @@ def init_with_selfcheck(torch, dist, lib, world, rank, local):
     bad = [e for e in info if e["lzgpu_device_index"] != e["local_rank"]]
     mv = [moved]
     dist.broadcast_object_list(mv, src=0)
+    # (what a rank's library on the wrong device would take: a HIP context and its sequence / chunk buffers, gigabytes; RCCL may map a few
+    # tens of MiB of peer buffers on device 0 meanwhile: the figure is reported, the run stops above 512 MiB)
     rec = {"ranks": info, "devices_visible": ndev, "ranks_share_a_device": shared, "device0_free_bytes_moved_while_other_ranks_initialised": mv[0],
-           "ok": not bad and (shared or world == 1 or mv[0] is None or mv[0] < (64 << 20))}
+           "ok": not bad and (shared or world == 1 or mv[0] is None or mv[0] < (512 << 20))}
     if not rec["ok"]:
         raise RuntimeError("bench.py --gpus %d: device binding self-check failed: %r" % (world, rec))
     return rec

@@ -569,8 +569,10 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             r.A = A; r.K = K; r.cut = cut;
         });
         // 64-lane exclusive scan of the block summaries, x0 = -inf (:3679 "i = negInf")
-        if constexpr (BOUNDS) i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
-        else                  i_last = x.uni(x.scan_gap_plain(sh, LZ_DP_NEGINF, gapE, cpl, RYi - LY0));    // (no masked cell: cut == 0, K = gapE per cell)
+        // (a row without a masked cell -- every row of a DP without bounds, and the rows of the others on which no mask piece is in reach --
+        // has cut == 0 and K = gapE per cell in every lane: the closed form of the scan; any_active is uniform)
+        if (BOUNDS && any_active) i_last = x.uni(x.scan_gap(sh, LZ_DP_NEGINF));
+        else                      i_last = x.uni(x.scan_gap_plain(sh, LZ_DP_NEGINF, gapE, cpl, RYi - LY0));
         const u64 tb_ = LZ_PHASE_CLOCK();
         // walk 2: the cells (:3697-3767 without the prune test), candidate bests
         x.step([&](int lane, LzDpLane& r) {

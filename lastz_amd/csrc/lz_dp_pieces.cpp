@@ -93,8 +93,9 @@ struct Walk {
         if (last > (s64)cr) out.push_back(LzDpPiece{ cr + 1, (u32)last, x, 0u });
         return last;
     }
-    // the segments of alignment ai from the row it enters the list on (update_active_segs, :4885-4965)
-    void masks_of(s32 ai, u32 row, std::vector<LzDpPiece>& out) const
+    // the segments of alignment ai from the row it enters the list on (update_active_segs, :4885-4965); -> false if the horizon cut it short
+    bool seg_has_next(const LzDpAlign& A, s32 seg) const { return J.reversed ? seg > A.first_seg : seg < A.last_seg; }
+    bool masks_of(s32 ai, u32 row, std::vector<LzDpPiece>& out) const
     {
         const LzDpAlign& A = S.aligns[ai];
         s32 seg = J.reversed ? A.last_seg : A.first_seg;
@@ -102,16 +103,16 @@ struct Walk {
         s64 last = entry(seg, cr, out);
         for (;;) {
             const s64 e = std::max<s64>(last, cr) + 1;             // the first row the entry's segment no longer reaches: the list moves on
-            if (e > (s64)H) return;
+            if (e > (s64)H) return seg_has_next(A, seg) ? false : true;   // (rows beyond the horizon: more pieces only if segments remain)
             seg = J.reversed ? ((seg > A.first_seg) ? seg - 1 : -1) : ((seg < A.last_seg) ? seg + 1 : -1);
-            if (seg < 0) return;                                   // the alignment is behind the sweep
+            if (seg < 0) return true;                              // the alignment is behind the sweep
             cr = (u32)e;
             if (S.segs[seg].type == LZ_HORZ_SEG) {                 // its run of cells on this row, and straight on to the segment behind it
                 const LzDpSeg& g = S.segs[seg];
                 const s32 x = J.reversed ? LZ_SD(a2(), g.e2) : LZ_SD(g.b2, a2()), xe = J.reversed ? LZ_SD(a2(), g.b2) : LZ_SD(g.e2, a2());
                 if (xe >= x) out.push_back(LzDpPiece{ cr, cr, x, (u32)(xe - x) << 1 });
                 seg = J.reversed ? seg - 1 : seg + 1;              // (a horizontal piece is never terminal)
-                if (seg < A.first_seg || seg > A.last_seg) return;
+                if (seg < A.first_seg || seg > A.last_seg) return true;
             }
             last = entry(seg, cr, out);
         }
@@ -147,7 +148,7 @@ void lzh_dp_pieces(const LzHostSnapshot& S, const LzDpJob& J, u32 horizon, LzDpP
         const u32 r = J.reversed ? J.anchor1 - A.end1 : A.pos1 - J.anchor1;      // (unsigned, as the reference has it)
         if (r < fired) break;                                    // the head of the list is behind the sweep: nothing enters any more
         if (r > horizon) { out.complete = false; break; }
-        w.masks_of(order[(size_t)pos], r, out.mk);
+        if (!w.masks_of(order[(size_t)pos], r, out.mk)) out.complete = false;
         fired = r;
     }
     std::stable_sort(out.mk.begin(), out.mk.end(), [](const LzDpPiece& a, const LzDpPiece& b) { return a.r0 < b.r0; });

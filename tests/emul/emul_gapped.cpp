@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "../../lastz_amd/csrc/lz_gapped_host.hpp"
 #include "../../lastz_amd/csrc/lz_host.hpp"
 
@@ -58,6 +59,10 @@ struct CpuPhases {                      // X for lz_dp_run: a phase = the lambda
     }
 };
 
+u32 emul_verify_pieces(const LzHostSnapshot& S, const LzDpJob& J, u32 horizon, u32 rows);   // emul_bounds_plain.cpp
+static u64 g_pieces_verified = 0;
+extern "C" u64 emul_gapped_pieces_verified(void) { return g_pieces_verified; }
+
 struct EmulExec : LzDpExecutor {
     std::vector<u8> tdp, qdp;           // padded DP-class codes
     u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
@@ -70,7 +75,14 @@ struct EmulExec : LzDpExecutor {
         static LzDpShared sh;
         const bool bounded = !snap.aligns.empty();
         static const u32 first_horizon = []() { const char* e = getenv("EMUL_DP_HORIZON"); return (u32)(e ? atoi(e) : 0); }();   // tests: a short one, to run into the re-run
+        static const bool verify = getenv("EMUL_VERIFY_PIECES") != nullptr;      // every job's pieces against the reference's row-by-row routines
         for (size_t k = 0; k < jobs.size(); k++) {
+            if (verify && bounded)
+                for (u32 h : { 61u, 776u, jobs[k].M }) {
+                    const u32 bad = emul_verify_pieces(snap, jobs[k], h, std::min<u32>(jobs[k].M, 6000u));
+                    if (bad) { fprintf(stderr, "emul: pieces of job %zu (anchor %u %u) differ from the row-by-row routines at row %u (horizon %u)\n", k, jobs[k].anchor1, jobs[k].anchor2, bad, h); return LZGPU_ERR_STATE; }
+                    g_pieces_verified++;
+                }
             u32 slot = tb_slot;
             u32 horizon = first_horizon ? first_horizon : jobs[k].M;
             for (;;) {

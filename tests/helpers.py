@@ -110,7 +110,7 @@ def build_emul(tag="", flags=()):
     import subprocess
     emul = os.path.join(ROOT, "tests", "emul"); cs = os.path.join(ROOT, "lastz_amd", "csrc")
     so = os.path.join(emul, "libemul%s.so" % ("_" + tag if tag else ""))
-    srcs = [os.path.join(emul, "emul_seed.cpp"), os.path.join(emul, "emul_gapped.cpp"),
+    srcs = [os.path.join(emul, "emul_seed.cpp"), os.path.join(emul, "emul_gapped.cpp"), os.path.join(emul, "emul_bounds_plain.cpp"),
             os.path.join(cs, "lz_host.cpp"), os.path.join(cs, "lz_gapped_host.cpp"), os.path.join(cs, "lz_dp_pieces.cpp")]
     deps = srcs + [os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "lzgpu.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):

@@ -122,6 +122,29 @@ def test_a_sweep_that_passes_its_piece_horizon_is_run_again():
     assert p.returncode == 0 and "reruns" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+def test_pieces_equal_the_references_row_by_row_bookkeeping():
+    """lz_dp_pieces.cpp evaluates a DP's bounds and masked cells segment by segment; tests/emul/emul_bounds_plain.cpp restates the
+    reference's routines as they stand (update_LR_bounds, next / prev_sweep_seg, update_active_segs, build_active_seg: one call per
+    row).  Every job of the obstacle course and of the overlapping-alignment cases -- forward and backward sweeps, bounds that hop and
+    die, alignments entering the list -- row by row, with the pieces asked for up to 61 rows, 776 rows and the job's last row."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H, test_emul_gapped as T\n"
+            "lib = C.CDLL(H.build_emul()); lib.emul_gapped_extend.argtypes = T.ARGTYPES; lib.emul_gapped_pieces_verified.restype = C.c_uint64\n"
+            "t, q = H.load_case('adversarial')\n"
+            "T._check(lib, t[9000:14500], q[29500:34000])\n"
+            "t, q = H.load_case('synth_overlap')\n"
+            "for kw in (dict(), dict(gap_open=200, gap_extend=60, ydrop=5000), dict(tb_len=1 << 20)):\n"
+            "    T._check(lib, t, q, **kw)\n"
+            "n = lib.emul_gapped_pieces_verified()\n"
+            "assert n > 1500, n\n"
+            "print('verified', n)\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ); env["EMUL_VERIFY_PIECES"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=2400)
+    assert p.returncode == 0 and "verified" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_indexed_neighbour_search_equals_plain_walk(L):
     """msp_left_right with the running-max index vs the reference's walk, random snapshots (incl. > 64 overlaps)"""
     L.emul_selftest_neighbours.restype = C.c_int
