@@ -1101,7 +1101,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: no live rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE over a child process); roofline.traffic then replays the committed table")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pair-file", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--time-budget-s", type=float, default=1200.0, help="N > 1: warm-up + timed steps are cut to fit (a step is the whole 3 Gbp job)")
+    ap.add_argument("--time-budget-s", type=float, default=420.0, help="N > 1: warm-up + timed steps are cut to fit (a step is the whole 3 Gbp job)")
     a = ap.parse_args()
     if a.north_star:
         a.tlen = a.qlen = 200_000_000

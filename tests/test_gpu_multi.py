@@ -55,7 +55,9 @@ def test_two_ranks_merge_to_the_single_process_and_reference_output(pair, name):
     # both ranks worked, each on its own units, and the hot path ran on the GPU
     assert sorted(u for p in plan for u in p) == [(i, s) for i in range(3) for s in (0, 1)] and all(plan)
     assert "[lzgpu] table: shared with the other ranks" in errs[0] and "[lzgpu] table: received from rank 0" in errs[1]
+    assert multi.run.last["devices_bound"] == [0, 0]             # the start-up self-check: every rank printed the device the launcher gave it
     for r in (0, 1):
+        assert "[lzgpu] rank %d of 2: device 0" % r in errs[r]
         assert errs[r].count("[lzgpu] search: done on the GPU") == len(plan[r])
         loaded = len({qi for qi, _ in plan[r]})                  # a rank reads only the sequences it owns a strand of
         assert errs[r].count("[lzgpu] search: unit of another rank") == 2 * loaded - len(plan[r])
@@ -140,6 +142,19 @@ def _bench(args, nproc, port, env_extra=None, timeout=900):
 
 
 SHAPE = ["--steps", "1", "--warmup", "0", "--tlen-multi", "4000000", "--q-units", "3", "--q-unit-len", "1500000", "--no-cpu-baseline"]
+
+
+@needs_bins
+def test_a_rank_that_is_not_on_the_device_it_was_given_stops_the_run(pair):
+    """the self-check's other half: a launcher that hands rank 1 a device the box does not have (LOCAL_RANK=1 wraps to device 0 here)
+    must not get a quiet run on the wrong GPU -- the shim stops the rank, the launcher the job"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one visible device")
+    t, q = str(pair / "t.fa"), str(pair / "q.fa")
+    with pytest.raises(RuntimeError) as e:
+        multi.run(t, q, ["--nogapped"], ranks=2, lastz=GPU_BIN, devices=[0, 1], transport="file", env={"LZGPU_SHARE_TIMEOUT_S": "20"})
+    assert "LOCAL_RANK=1" in str(e.value) or "rank 1" in str(e.value)
 
 
 def test_bench_two_ranks_search_and_gapped_stage_equal_one_rank():
