@@ -79,7 +79,10 @@ struct LzCtx {
 
     // ---- seed-search scratch
     DevBuf cnt, off, pk;            // per query position: raw-hit count (u32), exclusive scan (u64), packed word (u32)
-    DevBuf wiv, wsk, wsv;           // position index; (word, position) sorted by word
+    DevBuf wiv, wsk, wsv;           // position index; (block of positions | word, position) sorted by that key (seed_kernels.hip: k_pack_words)
+    DevBuf blk_start;               // where each block of positions begins in the sorted list
+    std::vector<u64> blk_start_host;
+    u32 blk_shift = 0, blk_count = 1;
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
     DevBuf bins[LZ_SETS];           // the partition (high hash byte) of every hit of the chunk, written beside the keys
     DevBuf keys[LZ_SETS];                 // hit keys of a chunk, discovery order (two sets of every per-chunk buffer: the chunk pipeline)

@@ -529,7 +529,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             u32 vbb[LZ_DP_BATCH];
             LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                 const u32 rx = LZ_RING(base + k);
-                vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if constexpr (BOUNDS) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];
+                vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if (BOUNDS && any_active) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];   // (any_active is uniform: no stamp is read on a row without a mask piece in reach)
             }
             LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
         };

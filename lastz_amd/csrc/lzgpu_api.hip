@@ -577,6 +577,8 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         c.pinned_words = (size_t)ns + 16;
     }
     if ((rc = lzk_sample_offsets(c, c.off.as<u64>(), c.cnt.as<u32>(), n, S, ns, c.pinned))) return rc;
+    c.blk_start_host.assign((size_t)c.blk_count + 1, 0);       // (a chunk's launch of the fill kernel covers its blocks' range of the sorted list)
+    LZ_HIP(hipMemcpyAsync(c.blk_start_host.data(), c.blk_start.p, ((size_t)c.blk_count + 1) * 8, hipMemcpyDeviceToHost, c.stream));
     LZ_HIP(hipStreamSynchronize(c.stream));
     g_hp.lap(1, "count+scan (sync)");
     c.timer.resolve();

@@ -203,8 +203,16 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries)
 // the 13 probe streams (word ^ flip) moves through wstart[] / wpos[] front to back.  What is written --
 // cnt[position] and the hits at off[position] -- is indexed by position, so the discovery order of the
 // hits is untouched.
+// The sort key of a query position is (block of the position) << kbits | word, kbits = weight + 1: the list is word-sorted INSIDE blocks of
+// 2^bshift consecutive positions (at most 16 blocks).  What the fill kernel writes goes to off[position]: with one word order over the
+// whole query a wave's 64 positions scatter their runs of keys over the whole key array of the chunk (15.5 GB for a 50 Mbp strand),
+// three new pages per position -- and k_fill_hits2 took 18 or 28 ms from one process to the next on the same box, depending on what
+// physical pages its buffers got.  Inside a block the destinations stay within 1/16 of the arrays, the probes still move front to back
+// through the table (3-4 words between neighbouring entries: the lines of wstart[] are still shared), and a chunk of query positions is a
+// contiguous range of blocks, hence of the sorted list: its launch covers that range only (a 200 Mbp strand has 29 chunks; every one of
+// their launches used to read the whole list to find its 1/29).
 __global__ void __launch_bounds__(LZ_TPB)
-k_pack_words(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd, u32* __restrict__ pk, u32* __restrict__ iv)
+k_pack_words(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd, u32* __restrict__ pk, u32* __restrict__ iv, u32 bshift, u32 kbits)
 {
     // the block's LZ_TPB windows overlap in all but one byte: the codes go through LDS once
     __shared__ u8 win[LZ_TPB + 32];
@@ -218,17 +226,20 @@ k_pack_words(const u8* __restrict__ qcode, u32 lo, u32 hi, LzSeedDev sd, u32* __
         u64 w = 0; u32 bad = 0;
         for (u32 k = 0; k < L; k++) { const u32 c = win[threadIdx.x + k]; bad |= c; w = (w << 2) | LZ_CODE_BITS(c); }
         const bool valid = pos2 >= lo + L && !(bad & LZ_CODE_INVALID);     // window inside the interval, only ACGT
-        pk[i] = valid ? lz_apply_seed(sd, w) : (1u << sd.weight);   // "no word" sorts after every real word
+        pk[i] = ((i >> bshift) << kbits) | (valid ? lz_apply_seed(sd, w) : (1u << sd.weight));   // "no word" sorts after every real word of its block
         iv[i] = i;
     }
 }
-
-// "words in seq 2" (the reference's counter): the entries of the sorted list in front of the first "no word"
-__global__ void k_count_words(const u32* __restrict__ sk, u32 n, u32 none, u64* __restrict__ n_words)
+// where the blocks begin in the sorted list: bs[b] = first entry whose key's block is >= b, b in [0, nblk]; and "words in seq 2" (the
+// reference's counter): inside a block the entries without a word (key's word field == none) sort behind those with one
+__global__ void k_block_starts(const u32* __restrict__ sk, u32 n, u32 kbits, u32 none, u32 nblk, u64* __restrict__ bs, u64* __restrict__ n_words)
 {
-    u32 a = 0, b = n;
-    while (a < b) { const u32 m = a + ((b - a) >> 1); if (sk[m] < none) a = m + 1; else b = m; }
-    *n_words += a;
+    const u32 b = threadIdx.x;
+    if (b > nblk) return;
+    auto first_at_least = [&](u64 key) { u32 lo = 0, hi = n; while (lo < hi) { const u32 m = lo + ((hi - lo) >> 1); if ((u64)sk[m] < key) lo = m + 1; else hi = m; } return lo; };
+    const u32 start = first_at_least((u64)b << kbits);
+    bs[b] = start;
+    if (b < nblk) atomicAdd((unsigned long long*)n_words, (unsigned long long)(first_at_least(((u64)b << kbits) | none) - start));
 }
 
 __global__ void __launch_bounds__(LZ_TPB)
@@ -237,7 +248,7 @@ k_count_sorted(const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, Lz
 {
     const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
     if (j >= n) return;
-    const u32 w0 = sk[j];
+    const u32 w0 = sk[j] & ((2u << sd.weight) - 1u);            // (the key's low weight + 1 bits: the word, or "no word")
     if (w0 >> sd.weight) return;                                // no word at this position: cnt stays 0
     u32 c = 0;
     for (int p = 0; p < sd.nprobes; p++) { const u32 w = w0 ^ sd.probe_xor[p]; c += wstart[w + 1] - wstart[w]; }
@@ -256,7 +267,7 @@ k_count_sorted_owned(const u32* __restrict__ sk, const u32* __restrict__ sv, u32
 {
     const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;
     if (j >= n) return;
-    const u32 w0 = sk[j];
+    const u32 w0 = sk[j] & ((2u << sd.weight) - 1u);
     if (w0 >> sd.weight) return;
     const u32 i = sv[j], pos2 = lo + i + 1;
     u32 c = 0;
@@ -271,20 +282,37 @@ int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk,
 {
     const u32 n = hi - lo;
     LZ_HIP(hipMemsetAsync(cnt, 0, (size_t)n * 4, c.stream));
+    // blocks of positions (k_pack_words): at most 16, fewer for the heaviest seeds (the key is 32 bits)
+    const u32 kbits = (u32)c.seed.weight + 1u;
+    // ... and only for a search that will need several chunks (measured: with one chunk per strand the blocks buy nothing -- the fill
+    // kernel's 18-or-28 ms do not come from the range of its scatter -- and cost k_count_hits 0.8 ms of shared wstart[] lines; at 200 Mbp,
+    // 29 chunks per strand, the launches' ranges take the fill from 292 to 232 ms per step): twice as many blocks as expected chunks
+    static const int force_bits = []() { const char* e = getenv("LZGPU_BLOCK_BITS"); const int v = e ? atoi(e) : -1; return v > 7 ? 7 : v; }();   // A/B
+    const double est_hits = (double)n * (double)c.num_words * (double)c.seed.nprobes / (double)(1ull << c.seed.weight);
+    u32 want_bits = 0;
+    while (want_bits < 5 && est_hits > (double)c.hit_capacity * (double)(1u << want_bits) * 0.5) want_bits++;
+    if (est_hits <= (double)c.hit_capacity) want_bits = 0;
+    if (force_bits >= 0) want_bits = (u32)force_bits;
+    u32 bbits = std::min<u32>(want_bits, 32u - kbits);
+    u32 bshift = 0;
+    const u64 nm1 = n ? (u64)n - 1 : 0;
+    while (bshift < 32 && (nm1 >> bshift) >= (1ull << bbits)) bshift++;
+    c.blk_shift = bshift; c.blk_count = (u32)((nm1 >> bshift) + 1);
     c.timer.begin("k_pack_words", c.stream);
     hipLaunchKernelGGL(k_pack_words, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
-                       qcode, lo, hi, c.seed, pk, iv);
+                       qcode, lo, hi, c.seed, pk, iv, bshift, kbits);
     c.timer.end(c.stream);
     LZ_HIP(hipGetLastError());
     size_t tmp = 0;
-    const unsigned bits = (unsigned)c.seed.weight + 1u;
+    const unsigned bits = kbits + bbits;
     LZ_HIP(rocprim::radix_sort_pairs(nullptr, tmp, pk, sk, iv, sv, (size_t)n, 0u, bits, c.stream));
     int rc = c.sort_tmp.ensure(tmp);
     if (rc) return rc;
     c.timer.begin("rocprim_sort_words", c.stream);
     LZ_HIP(rocprim::radix_sort_pairs(c.sort_tmp.p, tmp, pk, sk, iv, sv, (size_t)n, 0u, bits, c.stream));
     c.timer.end(c.stream);
-    hipLaunchKernelGGL(k_count_words, dim3(1), dim3(1), 0, c.stream, sk, n, 1u << c.seed.weight, valid_words_dev);
+    if ((rc = c.blk_start.ensure(130 * 8))) return rc;
+    hipLaunchKernelGGL(k_block_starts, dim3(1), dim3(192), 0, c.stream, sk, n, kbits, 1u << c.seed.weight, c.blk_count, c.blk_start.as<u64>(), valid_words_dev);
     c.timer.begin("k_count_hits", c.stream);
     if (c.n_owners > 1)
         hipLaunchKernelGGL(k_count_sorted_owned, dim3((n + LZ_TPB - 1) / LZ_TPB), dim3(LZ_TPB), 0, c.stream,
@@ -345,9 +373,9 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             u64 base, u64* __restrict__ keys, u8* __restrict__ bins, u32 n_owners, u32 owner)
 {
     const u32 lane = threadIdx.x & 63u, p = lane & (LZ_FILL_GROUP - 1), g = lane >> 4;
-    const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane
+    const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane (sk / sv: the chunk's range of the list)
     u32 w_l = 0, i_l = 0; bool in = false;
-    if (j < n) { w_l = sk[j]; i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
+    if (j < n) { w_l = sk[j] & ((2u << sd.weight) - 1u); i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
     u64 todo = __ballot(in);
     while (todo) {                                              // wave-uniform
         // the next four entries of the wave, one per 16-lane group
@@ -466,9 +494,9 @@ k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
     LzFill2Wave& sh = shw[threadIdx.x >> 6];
     unsigned short* const own = reinterpret_cast<unsigned short*>(sh.own32);
     const u32 lane = threadIdx.x & 63u;
-    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;           // one sorted entry per lane
+    const u32 j = blockIdx.x * LZ_TPB + threadIdx.x;           // one sorted entry per lane (sk / sv: the chunk's range of the list)
     u32 w_l = 0, i_l = 0; bool in = false;
-    if (j < n) { w_l = sk[j]; i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
+    if (j < n) { w_l = sk[j] & ((2u << sd.weight) - 1u); i_l = sv[j]; in = !(w_l >> sd.weight) && i_l >= i0 && i_l < i1; }
     if (!__ballot(in)) return;                                  // (wave-uniform: nothing of this chunk among the wave's entries)
     const u32 dbase = in ? (u32)(off[i_l] - base) : 0u;         // (hit indices inside a chunk are 32-bit)
     const u32 pos2 = lo + i_l + 1u;
@@ -562,6 +590,13 @@ k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
 int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st)
 {
     if (n == 0 || i1 <= i0) return 0;
+    // the chunk's positions [i0, i1) lie in blocks i0 >> shift .. (i1 - 1) >> shift: a contiguous range of the sorted list
+    if (!c.blk_start_host.empty()) {
+        const u32 b0 = i0 >> c.blk_shift, b1 = (i1 - 1) >> c.blk_shift;
+        const u64 j0 = c.blk_start_host[b0], j1 = c.blk_start_host[std::min<u32>(b1 + 1, c.blk_count)];
+        sk += j0; sv += j0; n = (u32)(j1 - j0);
+        if (n == 0) return 0;
+    }
     c.timer.begin("k_fill_hits", st);
     if (c.n_owners > 1)
         hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
@@ -943,20 +978,23 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
     if (lane == 0) n_tasks[region] = my_n < region_cap ? my_n : region_cap;
 }
 
+#ifndef LZ_ST_TPB
+#define LZ_ST_TPB 512                                // lanes per workgroup of k_scan_tasks: two workgroups share a CU (the tables are 64 KiB of LDS), 16 waves per CU (256: 5.3 ms per step, 512: 4.4, 1024: 4.2)
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LZ_ST_TPB)
 k_scan_tasks(LzExtendParams P, LzLutParams Q, const LzLutEntry* __restrict__ lut_g, const s32* __restrict__ score_tab_g, const LzScanTask* __restrict__ tasks,
              const u32* __restrict__ n_tasks, u32 n_regions, u32 region_cap, u32* __restrict__ summ)
 {
     __shared__ LzLutEntry lut[LZ_LUT_TOTAL];
     __shared__ s32 ctab[MODE == 1 ? LZ_NCLASS * LZ_NCLASS : 1];
-    for (u32 k = threadIdx.x; k < LZ_LUT_TOTAL; k += 256) lut[k] = lut_g[k];
-    if (MODE == 1) for (u32 k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += 256) ctab[k] = score_tab_g[k];
+    for (u32 k = threadIdx.x; k < LZ_LUT_TOTAL; k += LZ_ST_TPB) lut[k] = lut_g[k];
+    if (MODE == 1) for (u32 k = threadIdx.x; k < LZ_NCLASS * LZ_NCLASS; k += LZ_ST_TPB) ctab[k] = score_tab_g[k];
     __syncthreads();
     constexpr bool SP = MODE == 1;
     for (u32 region = blockIdx.x; region < n_regions; region += gridDim.x) {
         const u32 nt = n_tasks[region];
-        for (u32 k = threadIdx.x; k < nt; k += 256u) {
+        for (u32 k = threadIdx.x; k < nt; k += (u32)LZ_ST_TPB) {
             const LzScanTask t = tasks[(size_t)region * region_cap + k];
             LzLutScan L = t.L, R = t.R;
             while (L.alive == 1 && L.nwin < (u32)LZ_LUT_MAXWIN) lz_lut_step<false, SP>(Q, lut, t.diag, L, ctab);
@@ -1114,8 +1152,8 @@ int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const Lz
     LZ_HIP(hipGetLastError());
     if (mode < 2) {
         c.timer.begin("k_scan_tasks", st);
-        if (mode == 0) hipLaunchKernelGGL(k_scan_tasks<0>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
-        else           hipLaunchKernelGGL(k_scan_tasks<1>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(256), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
+        if (mode == 0) hipLaunchKernelGGL(k_scan_tasks<0>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(LZ_ST_TPB), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
+        else           hipLaunchKernelGGL(k_scan_tasks<1>, dim3(std::min<u32>(n_regions, 4u * (u32)cus)), dim3(LZ_ST_TPB), 0, st, P, Q, lut, score_tab, tasks, ntk, n_regions, task_cap, summ);
         c.timer.end(st);
         LZ_HIP(hipGetLastError());
     }
