@@ -336,7 +336,9 @@ struct HipDpExec : LzDpExecutor {
                                    problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
             }
             if (!ids_bound.empty()) {
-                auto bkern = P.no_trim ? k_ydrop<true, true, false> : k_ydrop<false, true, false>;
+                bool brepl = n <= 2u * (u64)LZ_DP_WPE * (u64)c.num_cus;             // (the later rounds of a strand: a handful of DPs, each alone on its CU)
+                if (const char* e = getenv("LZGPU_DP_REPL")) brepl = e[0] == '1';
+                auto bkern = P.no_trim ? (brepl ? k_ydrop<true, true, true> : k_ydrop<true, true, false>) : (brepl ? k_ydrop<false, true, true> : k_ydrop<false, true, false>);
                 hipLaunchKernelGGL(bkern, dim3((unsigned)ids_bound.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
                                    problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
             }

@@ -276,7 +276,7 @@ LZ_HD s32 lz_dp_piece_at(const LzDpPiece& p, u32 row) { return p.x0 + ((p.fl & 1
 // BOUNDS: the problem has earlier alignments (bounds to follow, segments to mask).  Without any -- the first round of a
 // strand, where the longest DPs run -- the two routines of the row set-up, the mask stamps and their tests in the walks
 // drop out at compile time (7.2 k -> 6.7 k cycles per row with the routines skipped by a run-time test alone).
-// REPLICATE (only without BOUNDS): see REPL below.
+// REPLICATE: see REPL below.
 template <bool NOTRIM, bool BOUNDS, bool REPLICATE, class X, class SH>
 LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
@@ -302,13 +302,13 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
     // REPL: every wave keeps its own copy of the sweep state and runs the serial piece itself, on identical inputs.  One
     // wave doing it for all costs a barrier, sixteen words written to LDS and read back by the others, per row; the
     // copies cost nothing (the other three waves were waiting).  What the piece writes to LDS is the same from every
-    // wave and each wave reads its own writes; only the list of active segments is updated in place, so this is for
-    // problems without bounds.  Global stores stay with one wave.
+    // wave and each wave reads its own writes.  Global stores stay with one wave.  (Rounds 3-4 could replicate only the DPs without
+    // bounds: the list of active segments was updated in place.  The pieces of round 5 are read-only: every wave keeps its own cursors.)
     // The copies are not free when a CU is full: a SIMD issues one scalar instruction per four cycles whichever wave it
     // comes from, and with seven DPs per CU every SIMD then carries seven copies of the piece instead of two (bench
     // pair, both strands in one launch of 4468 DPs: 72.2 ms against 70.4 with one leading wave; one strand's 2300 DPs,
     // whose launch lasts as long as its longest DP: 0.145 against 0.161 s for the two stages).  The launcher picks.
-    constexpr bool REPL = !BOUNDS && REPLICATE;
+    constexpr bool REPL = REPLICATE;
     LzDpCtl ct;                                                 // lane 0's (REPL: every wave's)
     // ---- set-up + row 0 (:3500-3605)
     auto setup = [&]() {
@@ -434,8 +434,6 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                 if (ct.rbi < J.n_rb) { ct.R = lz_dp_piece_at(ct.rb, ct.row); ct.RY = lz_dp_special_min(ct.RY, ct.R); }
             }
             q3 = LZ_PHASE_CLOCK();
-            if (BOUNDS && SH::STAMP_WRAPS && ct.row > 1 && SH::stamp(ct.row) == 1u)   // the 16-bit stamps start over: none of the old ones may survive
-                for (u32 k = 0; k < SH::RING; k++) sh.mk[k] = 0;
             if (BOUNDS) {
                 // the mask pieces in reach of the row (update_active_segs, :4885-4965): those that have begun, from the first that has not ended
                 while (ct.mk_hi < J.n_mk && ct.mk_next_r0 <= ct.row) { ct.mk_hi++; if (ct.mk_hi < J.n_mk) ct.mk_next_r0 = x.uni(pc_mk[ct.mk_hi].r0); }
@@ -468,6 +466,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
         u32 e_on, mk_lo_now = 0, mk_hi_now = 0;
         if (REPL) {
             finished = x.uni(ct.done) != 0u; e_on = p_extra;
+            if (BOUNDS) { mk_lo_now = x.uni(ct.mk_lo); mk_hi_now = x.uni(ct.mk_hi); }
             row = x.uni(ct.row); LY0 = x.uni(ct.LY); RYi = x.uni(p_ry_iter); cpl = x.uni(p_cpl); best0 = x.uni(ct.best); trow_cur = x.uni(p_trow_cur);
         } else {
             // the published words of every row, read together (two 128-bit reads and one wait), then the branches
@@ -500,6 +499,10 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
         swept = true;
         const bool any_active = BOUNDS && mk_hi_now > mk_lo_now;
         const u32 row_stamp = SH::stamp(row);
+        // the 16-bit stamps start over: none of the old ones may survive (all lanes, behind the previous row's last barrier; its own barrier
+        // before this row's stamps are written)
+        if (BOUNDS && SH::STAMP_WRAPS && row > 1 && row_stamp == 1u)
+            x.phase([&](int lane, LzDpLane&) { for (u32 k = (u32)lane; k < SH::RING; k += LZ_DP_LANES) sh.mk[k] = 0; });
         // The row's masked cells, stamped by the lanes: lane l takes pieces mk_lo + l, mk_lo + l + LANES, ... of those in reach; a piece
         // that covers the row masks x .. x + extra, clipped to the band (that also keeps the ring free of aliases: RY - LY < RING).
         // (build_active_seg, :4992-5035; the reference walks a linked list of segments here, one at a time.)

@@ -99,7 +99,7 @@ struct EmulExec : LzDpExecutor {
                 J.pc_off = 0; J.n_lb = (u32)pcs.lb.size(); J.n_rb = (u32)pcs.rb.size(); J.n_mk = (u32)pcs.mk.size();
                 J.horizon = pcs.complete ? 0xFFFFFFFFu : horizon;
                 CpuPhases x;
-                if (bounded) { if (no_trim) lz_dp_run<true, true, false>(x, sh, P, J, tab, &res[k]); else lz_dp_run<false, true, false>(x, sh, P, J, tab, &res[k]); }
+                if (bounded) { if (no_trim) (k & 1 ? lz_dp_run<true, true, true, CpuPhases, LzDpShared> : lz_dp_run<true, true, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, true, true, CpuPhases, LzDpShared> : lz_dp_run<false, true, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); }
                 else         { if (no_trim) (k & 1 ? lz_dp_run<true, false, true, CpuPhases, LzDpShared> : lz_dp_run<true, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, false, true, CpuPhases, LzDpShared> : lz_dp_run<false, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); }
                 if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
                     static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
