@@ -84,7 +84,7 @@ struct LzCtx {
     std::vector<u64> blk_start_host;
     u32 blk_shift = 0, blk_count = 1;
     u64* pinned = nullptr; size_t pinned_words = 0;   // host memory the device writes small results into (no staged D2H copies)
-    DevBuf bins[LZ_SETS];           // the partition (high hash byte) of every hit of the chunk, written beside the keys
+    DevBuf bins[LZ_SETS];           // the partition (high hash byte) of every hit of the chunk, written by the scan kernel (k_hist reads them)
     DevBuf keys[LZ_SETS];                 // hit keys of a chunk, discovery order (two sets of every per-chunk buffer: the chunk pipeline)
     DevBuf recs[LZ_SETS], bin_base[LZ_SETS];    // hit records partitioned by the high hash bits + the 257 partition offsets; two sets:
                                     // phase B of a chunk runs while the next chunk is filled / scanned / partitioned
@@ -126,7 +126,7 @@ int lzk_table_export(LzCtx& c, u32* last_dev, u32* prev_dev, u32 prev_entries);
 int lzk_count_hits(LzCtx& c, const u8* qcode, u32 lo, u32 hi, u32* cnt, u32* pk, u32* iv, u32* sk, u32* sv, u64* valid_words_dev);   // honours c.n_owners / c.owner
 int lzk_scan_counts(LzCtx& c, const u32* cnt, u64* off, u32 n);
 int lzk_sample_offsets(LzCtx& c, const u64* off, const u32* cnt, u32 n, u32 stride, u32 ns, u64* out);
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st);
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st);
 int lzk_hsp_match_counts(LzCtx& c, const LzHspRec* recs, const u32* n_rec_dev, u32 cap, u32 launch_for,
                          const u8* traw, const u8* qraw, const u8* tcode, const u8* qcode, u32* counts, hipStream_t s);
 struct LzLutParams; struct LzLutEntry;
@@ -138,7 +138,7 @@ int lzk_overlap32(LzCtx& c, const u8* src, u8* dst, size_t nblocks);
 int lzk_hist(LzCtx& c, const u8* bins, u64 n, u32* hist, u32* part, u32* bin_base, hipStream_t st);
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);
 int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                  const s32* score_tab, const LzLutEntry* lut, hipStream_t st);     // -> c.summ[set]
+                  const s32* score_tab, const LzLutEntry* lut, u8* bins, hipStream_t st);     // -> c.summ[set], and the partition byte of every hit -> bins
 int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, const u32* part, u64* recs, hipStream_t st);
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

@@ -693,7 +693,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
     for (auto& ch : chunks) {
         const int set = (int)(ci % (size_t)nsets);
         if (!a->extend) {                                       // process_for_plain_hit: report every hit
-            if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[0].as<u64>(), c.bins[0].as<u8>(), sF))) return rc;
+            if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[0].as<u64>(), sF))) return rc;
             std::vector<u64> hk(ch.nh);
             LZ_HIP(hipMemcpyAsync(hk.data(), c.keys[0].p, (size_t)ch.nh * 8, hipMemcpyDeviceToHost, c.stream));
             LZ_HIP(hipStreamSynchronize(c.stream));
@@ -704,15 +704,16 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
         if (reuse && pending == set) { if ((rc = settle(pending))) return rc; pending = -1; }   // (fewer than three sets)
         // F: keys + histogram (every buffer of the set is free once its phase B is done)
         if (reuse) LZ_HIP(hipStreamWaitEvent(sF, c.ev_extended[set], 0));
-        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[set].as<u64>(), c.bins[set].as<u8>(), sF))) return rc;
-        if ((rc = lzk_hist(c, c.bins[set].as<u8>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.bin_base[set].as<u32>(), sF))) return rc;
+        if ((rc = lzk_fill_hits(c, lo, ch.i0, ch.i1, c.wsk.as<u32>(), c.wsv.as<u32>(), n, c.off.as<u64>(), ch.base, c.keys[set].as<u64>(), sF))) return rc;
         LZ_HIP(hipEventRecord(c.ev_keys[set], sF));
         // S: the scans
         LZ_HIP(hipStreamWaitEvent(sS, c.ev_keys[set], 0));
-        if ((rc = lzk_scan_hits(c, set, mode, P, Q, c.keys[set].as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(), sS))) return rc;
+        if ((rc = lzk_scan_hits(c, set, mode, P, Q, c.keys[set].as<u64>(), ch.nh, c.score_tab.as<s32>(), c.lut.as<LzLutEntry>(), c.bins[set].as<u8>(), sS))) return rc;
         LZ_HIP(hipEventRecord(c.ev_summ[set], sS));
         // B: the partition
         LZ_HIP(hipStreamWaitEvent(sB, c.ev_summ[set], 0));
+        // (the tile histograms from the partition bytes the scan kernel left)
+        if ((rc = lzk_hist(c, c.bins[set].as<u8>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.bin_base[set].as<u32>(), sB))) return rc;
         if ((rc = lzk_partition(c, set, c.keys[set].as<u64>(), ch.nh, c.hist[set].as<u32>(), c.hist_part[set].as<u32>(), c.recs[set].as<u64>(), sB))) return rc;
         LZ_HIP(hipEventRecord(c.ev_part[set], sB));
         // S again: phase B of the previous chunk (diagEnd carries from chunk to chunk: chunk order)

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(LZ_TPB)
 k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32* __restrict__ wstart, const u32* __restrict__ wpos,
             const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
-            u64 base, u64* __restrict__ keys, u8* __restrict__ bins, u32 n_owners, u32 owner)
+            u64 base, u64* __restrict__ keys, u32 n_owners, u32 owner)
 {
     const u32 lane = threadIdx.x & 63u, p = lane & (LZ_FILL_GROUP - 1), g = lane >> 4;
     const u32 j = (blockIdx.x * LZ_TPB + threadIdx.x);         // one sorted entry per lane (sk / sv: the chunk's range of the list)
@@ -410,7 +410,7 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
             const u32 total = __shfl(incl, LZ_FILL_GROUP - 1, LZ_FILL_GROUP);
             if (OWNED) {
                 u64* o = out + carry + (incl - len);
-                for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) { const u64 kk = lz_hit_key(p1, pos2); bins[o - keys] = (u8)LZ_KEY_BIN(kk); *o++ = kk; } }
+                for (u32 jj = 0; jj < full; jj++) { const u32 p1 = wpos[a + jj]; if (lz_owned(p1, pos2, n_owners, owner)) *o++ = lz_hit_key(p1, pos2); }
             } else {
                 // The (up to) 64 lists of the wave -- 4 positions x 16 probes -- laid end to end: lane t takes hit t,
                 // t + 64, ... of that run, finds the list holding it (binary search over the lanes' running totals)
@@ -437,7 +437,7 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
                     const u32 ob_lo = (u32)__shfl((int)(u32)obase, (int)L), ob_hi = (u32)__shfl((int)(u32)((u64)obase >> 32), (int)L);
                     const u32 jj = t - (l_inc - l_len);
                     const s64 ob = (s64)(((u64)ob_hi << 32) | ob_lo);
-                    if (t < gtot) { const u64 kk = lz_hit_key(wpos[l_a + jj], l_pos2); keys[ob + (s64)t] = kk; bins[ob + (s64)t] = (u8)LZ_KEY_BIN(kk); }    // (the partition of every hit, one byte: k_hist reads these instead of the keys)
+                    if (t < gtot) keys[ob + (s64)t] = lz_hit_key(wpos[l_a + jj], l_pos2);
                 }
             }
             carry += total;
@@ -457,7 +457,7 @@ k_fill_hits(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
 //      concatenation -- leaves every cell with the id of the list that holds it: 16 marks and two passes over 128
 //      bytes per lane instead of a search per hit;
 //   3. lane t takes hits t, t + 64, ...: own[t] -> (list source - list start), (run's place in the key array - run
-//      start, pos2) from two small LDS tables -> one gather from wpos[], one key and one partition byte stored.  The
+//      start, pos2) from two small LDS tables -> one gather from wpos[], one key stored.  The
 //      stores of a wave are runs of consecutive keys (one run per position), as before.
 // A wave's LDS traffic is its own (no barrier: LDS operations of one wave execute in program order); concatenations
 // longer than LZ_F2_CAP hits (repeats) are taken in pieces; seeds with more than 16 probes in groups of 16.
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(LZ_TPB)
 k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
              const u32* __restrict__ wstart, const u32* __restrict__ wpos,
              const u32* __restrict__ sk, const u32* __restrict__ sv, u32 n, const u64* __restrict__ off,
-             u64 base, u64* __restrict__ keys, u8* __restrict__ bins)
+             u64 base, u64* __restrict__ keys)
 {
     __shared__ LzFill2Wave shw[LZ_TPB / 64];
     LzFill2Wave& sh = shw[threadIdx.x >> 6];
@@ -579,7 +579,7 @@ k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (ok[k]) { const u64 kk = lz_hit_key(p1[k], p2[k]); LZ_NT_ST(kk, keys + dst[k]); LZ_NT_ST((u8)LZ_KEY_BIN(kk), bins + dst[k]); }
+                    if (ok[k]) LZ_NT_ST(lz_hit_key(p1[k], p2[k]), keys + dst[k]);
             }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
         }
@@ -587,7 +587,7 @@ k_fill_hits2(u32 lo, u32 i0, u32 i1, LzSeedDev sd,
     }
 }
 
-int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, u8* bins, hipStream_t st)
+int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv, u32 n, const u64* off, u64 base, u64* keys, hipStream_t st)
 {
     if (n == 0 || i1 <= i0) return 0;
     // the chunk's positions [i0, i1) lie in blocks i0 >> shift .. (i1 - 1) >> shift: a contiguous range of the sorted list
@@ -600,15 +600,15 @@ int lzk_fill_hits(LzCtx& c, u32 lo, u32 i0, u32 i1, const u32* sk, const u32* sv
     c.timer.begin("k_fill_hits", st);
     if (c.n_owners > 1)
         hipLaunchKernelGGL(k_fill_hits<true>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, c.n_owners, c.owner);
+                           lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, c.n_owners, c.owner);
     else {
         static const bool old_fill = getenv("LZGPU_FILL_SHUFFLE") != nullptr;   // A/B aid: round 2's shuffle-search fill
         if (old_fill)
             hipLaunchKernelGGL(k_fill_hits<false>, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins, 1u, 0u);
+                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, 1u, 0u);
         else
             hipLaunchKernelGGL(k_fill_hits2, dim3((unsigned)(((u64)n + LZ_TPB - 1) / LZ_TPB)), dim3(LZ_TPB), 0, st,
-                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys, bins);
+                               lo, i0, i1, c.seed, c.wstart.as<u32>(), c.wpos.as<u32>(), sk, sv, n, off, base, keys);
     }
     c.timer.end(st);
     LZ_HIP(hipGetLastError());
@@ -857,7 +857,7 @@ template <int MODE> struct LzScanShared {
 template <bool SP>
 __device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzLutParams& Q, const LzLutEntry* lut, const s32* ctab, u64 key, bool valid,
                                               const LzLutRaw<SP>& rawl, const LzLutRaw<SP>& rawr, u32 idx, u32 lane,
-                                              u32* __restrict__ summ, LzScanTask* __restrict__ my_tasks, u32& my_n, u32 region_cap)
+                                              u32& summ_out, LzScanTask* __restrict__ my_tasks, u32& my_n, u32 region_cap)
 {
     constexpr bool HLIM = SP;
     s32 diag; LzLutScan L, R;
@@ -876,7 +876,7 @@ __device__ __forceinline__ void lz_scan_round(const LzExtendParams& P, const LzL
         }
         my_n += (u32)__popcll(mm);
     }
-    if (valid && !queued) LZ_NT_ST(lz_lut_summary(L, R, P.min_score), summ + idx);
+    summ_out = queued ? 0u : lz_lut_summary(L, R, P.min_score);          // (a queued hit's summary comes from k_scan_tasks, behind this kernel)
 }
 // The windows of a hit: 2 x 16 bytes of the target's 2-bit codes from the half-overlapping blocks (the left window starts at byte bl,
 // the right one at br = bl + 15 or 16, together at most 32 bytes: ONE line of t2x -- block bl / 32, offset bl % 32), 2 x 16 bytes of
@@ -908,7 +908,7 @@ template <int MODE, int TPB, int WPE>      // MODE 0: LUT scans, no special byte
 __global__ void __launch_bounds__(TPB, WPE)
 k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n,
             const s32* __restrict__ score_tab_g, const LzLutEntry* __restrict__ lut_g,
-            u32* __restrict__ summ, LzScanTask* __restrict__ tasks, u32* __restrict__ n_tasks, u32 region_cap)
+            u32* __restrict__ summ, u8* __restrict__ bins, LzScanTask* __restrict__ tasks, u32* __restrict__ n_tasks, u32 region_cap)
 {
     __shared__ LzScanShared<MODE> sh;
     const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -937,19 +937,30 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
 #pragma unroll 1
             for (u32 r = 0; r < LZ_SC_ROUNDS; r++) {
                 const u32 li = r * 64u + lane;
-                if (li < span_n) summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, keys[base + li]);
+                if (li < span_n) { const u64 kk = keys[base + li]; summ[base + li] = lz_probe_hit(P, sh.bc.tab, sh.bc.tab8, P.cls8 != 0, kk); bins[base + li] = (u8)LZ_KEY_BIN(kk); }
             }
         }
     } else if (span < nspans) {
-        // A wave takes 256 consecutive hits (a span), 64 per round.  The windows of a round are requested one round
-        // ahead into two register sets that take turns (no copies), the next span's keys two rounds ahead and its
-        // first windows during the span's last round: every load has a round of arithmetic to hide behind.
+        // A wave takes 256 consecutive hits (a span); a LANE takes four consecutive ones, one per round: its keys are two 16-byte loads,
+        // its four summaries one 16-byte store, its four partition bytes (for k_hist) one 4-byte store -- 64 consecutive bytes of a
+        // span's 256 went out per round when a lane's hits were 64 apart (the partition bytes as 64 one-byte stores: +2 ms on the 50 Mbp
+        // pair; the fill kernel used to write them beside its keys, in runs of ~39 bytes at random places, two partial lines each: 4-7 of
+        // its 19-26 ms).  The windows of a round are requested one round ahead into two register sets that take turns (no copies), the
+        // next span's keys two rounds ahead and its first windows during the span's last round: every load has a round of arithmetic to
+        // hide behind.
+        typedef u64 lz_u64x2 __attribute__((ext_vector_type(2)));
         auto load_keys = [&](u64 sp, u64& a0, u64& a1, u64& a2, u64& a3) {
             const u64 base = sp * SPAN;
             const u32 sn = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
-#define LZ_KEY_LD(p_) LZ_NT_LD(p_)
-            a0 = (lane < sn) ? LZ_KEY_LD(keys + base + lane) : 0ull;               a1 = (lane + 64u < sn) ? LZ_KEY_LD(keys + base + lane + 64u) : 0ull;
-            a2 = (lane + 128u < sn) ? LZ_KEY_LD(keys + base + lane + 128u) : 0ull; a3 = (lane + 192u < sn) ? LZ_KEY_LD(keys + base + lane + 192u) : 0ull;
+            const u32 l4 = 4u * lane;
+            const u64* kp = keys + base + l4;
+            if (l4 + 3u < sn) {
+                const lz_u64x2 x = LZ_NT_LD(reinterpret_cast<const lz_u64x2*>(kp)), y = LZ_NT_LD(reinterpret_cast<const lz_u64x2*>(kp + 2));
+                a0 = x.x; a1 = x.y; a2 = y.x; a3 = y.y;
+            } else {
+                a0 = (l4 < sn) ? LZ_NT_LD(kp) : 0ull;           a1 = (l4 + 1u < sn) ? LZ_NT_LD(kp + 1) : 0ull;
+                a2 = (l4 + 2u < sn) ? LZ_NT_LD(kp + 2) : 0ull;  a3 = 0ull;
+            }
         };
         u64 k0, k1, k2, k3;
         load_keys(span, k0, k1, k2, k3);
@@ -959,18 +970,31 @@ k_scan_hits(LzExtendParams P, LzLutParams Q, const u64* __restrict__ keys, u64 n
         for (;;) {
             const u64 base = span * SPAN;
             const u32 span_n = (n - base < (u64)SPAN) ? (u32)(n - base) : SPAN;
-            const u32 ib = (u32)base + lane;                     // (hit indices inside a chunk are 32-bit: lzgpu_set_hit_capacity)
+            const u32 l4 = 4u * lane;
+            const u32 ib = (u32)base + l4;                       // (hit indices inside a chunk are 32-bit: lzgpu_set_hit_capacity)
             const bool more_spans = span + wstride < nspans;
             u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+            u32 s0, s1, s2, s3;
             lz_scan_fetch<SP>(Q, k1, bl, br);
-            lz_scan_round<SP>(P, Q, lut, ctab, k0, lane < span_n, al, ar, ib, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k0, l4 < span_n, al, ar, ib, lane, s0, my_tasks, my_n, region_cap);
             if (more_spans) load_keys(span + wstride, n0, n1, n2, n3);
             lz_scan_fetch<SP>(Q, k2, al, ar);
-            lz_scan_round<SP>(P, Q, lut, ctab, k1, lane + 64u < span_n, bl, br, ib + 64u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k1, l4 + 1u < span_n, bl, br, ib + 1u, lane, s1, my_tasks, my_n, region_cap);
             lz_scan_fetch<SP>(Q, k3, bl, br);
-            lz_scan_round<SP>(P, Q, lut, ctab, k2, lane + 128u < span_n, al, ar, ib + 128u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k2, l4 + 2u < span_n, al, ar, ib + 2u, lane, s2, my_tasks, my_n, region_cap);
             if (more_spans) lz_scan_fetch<SP>(Q, n0, al, ar);
-            lz_scan_round<SP>(P, Q, lut, ctab, k3, lane + 192u < span_n, bl, br, ib + 192u, lane, summ, my_tasks, my_n, region_cap);
+            lz_scan_round<SP>(P, Q, lut, ctab, k3, l4 + 3u < span_n, bl, br, ib + 3u, lane, s3, my_tasks, my_n, region_cap);
+            const u32 pbytes = LZ_KEY_BIN(k0) | (LZ_KEY_BIN(k1) << 8) | (LZ_KEY_BIN(k2) << 16) | (LZ_KEY_BIN(k3) << 24);       // (the keys are still in their registers)
+            if (l4 + 3u < span_n) {
+                typedef u32 lz_u32x4 __attribute__((ext_vector_type(4)));
+                lz_u32x4 sv4; sv4.x = s0; sv4.y = s1; sv4.z = s2; sv4.w = s3;
+                LZ_NT_ST(sv4, reinterpret_cast<lz_u32x4*>(summ + ib));
+                LZ_NT_ST(pbytes, reinterpret_cast<u32*>(bins + ib));
+            } else {
+                if (l4 < span_n)      { summ[ib] = s0;      bins[ib] = (u8)pbytes; }
+                if (l4 + 1u < span_n) { summ[ib + 1u] = s1; bins[ib + 1u] = (u8)(pbytes >> 8); }
+                if (l4 + 2u < span_n) { summ[ib + 2u] = s2; bins[ib + 2u] = (u8)(pbytes >> 16); }
+            }
             if (!more_spans) break;
             span += wstride; k0 = n0; k1 = n1; k2 = n2; k3 = n3;
         }
@@ -1125,7 +1149,7 @@ int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n)
 }
 
 int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
-                  const s32* score_tab, const LzLutEntry* lut, hipStream_t st)
+                  const s32* score_tab, const LzLutEntry* lut, u8* bins, hipStream_t st)
 {
     if (n == 0) return 0;
     int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device);
@@ -1138,7 +1162,7 @@ int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const Lz
     u32* summ = c.summ[set].as<u32>(); LzScanTask* tasks = c.scan_tasks[set].as<LzScanTask>(); u32* ntk = c.scan_ntasks[set].as<u32>();
     c.timer.begin("k_scan_hits", st);
     const int tpb = lz_scan_tpb(mode);
-#define LZ_SCAN_LAUNCH(M_, T_, W_) hipLaunchKernelGGL((k_scan_hits<M_, T_, W_>), dim3(grid), dim3(T_), 0, st, P, Q, keys, n, score_tab, lut, summ, tasks, ntk, task_cap)
+#define LZ_SCAN_LAUNCH(M_, T_, W_) hipLaunchKernelGGL((k_scan_hits<M_, T_, W_>), dim3(grid), dim3(T_), 0, st, P, Q, keys, n, score_tab, lut, summ, bins, tasks, ntk, task_cap)
     if (mode == 0) {
         if (tpb == 640)       LZ_SCAN_LAUNCH(0, 640, 5);
         else if (tpb == 768)  LZ_SCAN_LAUNCH(0, 768, 6);
