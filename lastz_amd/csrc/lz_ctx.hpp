@@ -139,7 +139,6 @@ int lzk_hist(LzCtx& c, const u8* bins, u64 n, u32* hist, u32* part, u32* bin_bas
 int lzk_scan_reserve(LzCtx& c, int set, int mode, u64 max_n);
 int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const LzLutParams& Q, const u64* keys, u64 n,
                   const s32* score_tab, const LzLutEntry* lut, u8* bins, hipStream_t st);     // -> c.summ[set], and the partition byte of every hit -> bins
-u64 lzk_partition_slots(u64 n);
 int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, const u32* part, u64* recs, hipStream_t st);
 int lzk_settle(LzCtx& c, const LzExtendParams& P, const u64* recs, const u32* bin_base, u32* diag_end,
                const s32* score_tab, LzHspRec* out, u32* out_count, u32 out_cap, u64* counters, hipStream_t s);

@@ -615,7 +615,7 @@ extern "C" int lzgpu_seed_hit_search(const lz_search_args* a, lz_hsp** out, uint
             for (int k = 0; k < nsets; k++) {
                 if ((rc = c.keys[k].ensure((size_t)max_chunk * 8))) return rc;
                 if ((rc = c.bins[k].ensure((size_t)max_chunk + 64))) return rc;
-                if ((rc = c.recs[k].ensure((size_t)lzk_partition_slots(max_chunk) * 8))) return rc;
+                if ((rc = c.recs[k].ensure((size_t)max_chunk * 8))) return rc;
                 if ((rc = c.bin_base[k].ensure(257 * 4))) return rc;
                 if ((rc = c.hist[k].ensure(ntiles * 256 * 4))) return rc;
                 if ((rc = c.hist_part[k].ensure(nblocks * 256 * 4))) return rc;

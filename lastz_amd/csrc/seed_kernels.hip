@@ -741,9 +741,6 @@ void lz_phase_clocks_print() {}
 #define LZ_PP_TILE   (LZ_PP_TPB * LZ_PP_ROUNDS)      // hits per tile of k_hist / k_partition
 #define LZ_PP_QCAP   96                              // unfinished scans a tile can queue (beyond that the hit is left to phase B)
 #define LZ_NBIN      256
-#ifndef LZ_PP_PAD
-#define LZ_PP_PAD    1u                              // records a tile's share of a partition is padded to (8 = one 64-byte line; 1 = no padding)
-#endif
 
 // hist[tile][bin]: hits of the tile per partition
 __global__ void __launch_bounds__(LZ_TPB)
@@ -763,9 +760,7 @@ k_hist(const u8* __restrict__ bins, u64 n, u32* __restrict__ hist)
         }
     }
     __syncthreads();
-    // (LZ_PP_PAD: a tile's share of a partition is rounded up to whole 64-byte lines of records -- k_partition fills the rest with null
-    // records, which phase B skips -- so that no line of a partition's stream is written by two tiles, half each)
-    hist[(size_t)blockIdx.x * LZ_NBIN + threadIdx.x] = (cnt[threadIdx.x] + (LZ_PP_PAD - 1u)) & ~(LZ_PP_PAD - 1u);
+    hist[(size_t)blockIdx.x * LZ_NBIN + threadIdx.x] = cnt[threadIdx.x];
 }
 // per block of 256 tiles: exclusive prefix down each column, column sums to part[block][bin]
 __global__ void __launch_bounds__(LZ_NBIN)
@@ -1117,12 +1112,6 @@ k_partition(const u64* __restrict__ keys, const u32* __restrict__ summ, u64 n,
         const u32 b = (u32)(r >> 55) & 0xFFu;
         recs[(size_t)sh.gbase[b] + (k - sh.tstart[b])] = r & ~(0xFFull << 55);
     }
-    if (LZ_PP_PAD > 1u)                                         // null records up to the next line boundary of every partition's run
-        for (u32 k = tid; k < LZ_NBIN * LZ_PP_PAD; k += LZ_PP_TPB) {
-            const u32 b = k / LZ_PP_PAD, j = k % LZ_PP_PAD;
-            const u32 cnt = sh.tstart[b + 1] - sh.tstart[b], padded = (cnt + (LZ_PP_PAD - 1u)) & ~(LZ_PP_PAD - 1u);
-            if (cnt + j < padded) recs[(size_t)sh.gbase[b] + cnt + j] = ~0ull;
-        }
 }
 
 // grid of k_scan_hits for n hits, and the geometry of its task list: one region per wave, room for 1/32 of the
@@ -1195,8 +1184,6 @@ int lzk_scan_hits(LzCtx& c, int set, int mode, const LzExtendParams& P, const Lz
     return 0;
 }
 
-u64 lzk_partition_slots(u64 n)          // records a chunk of n hits can take in the partition streams (with the null records of LZ_PP_PAD)
-{ const u64 ntiles = (n + LZ_PP_TILE - 1) / LZ_PP_TILE; return n + ntiles * LZ_NBIN * (u64)(LZ_PP_PAD - 1u); }
 int lzk_partition(LzCtx& c, int set, const u64* keys, u64 n, const u32* hist, const u32* part, u64* recs, hipStream_t st)
 {
     if (n == 0) return 0;
