@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.environ.get("LZGPU_CSRC") or os.path.join(HERE, "csrc")      # (LZGPU_CSRC: a patched copy of the sources, tools/build_variant.sh)
 OUT = os.path.join(HERE, "liblzgpu.so")
-SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "window_kernels.hip", "lz_share.hip", "lz_host.cpp", "lz_gapped_host.cpp", "lz_dp_pieces.cpp", "lz_chain_host.cpp"]
+SOURCES = ["lzgpu_api.hip", "seed_kernels.hip", "dp_kernels.hip", "dp_kernels_narrow.hip", "window_kernels.hip", "lz_share.hip", "lz_host.cpp", "lz_gapped_host.cpp", "lz_dp_pieces.cpp", "lz_chain_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"] + os.environ.get("LZGPU_CXXFLAGS", "").split()
 
 
@@ -23,7 +23,7 @@ def build(force=False, verbose=False):
     out = OUT if not tag else os.path.join(HERE, "liblzgpu_%s.so" % tag)
     objdir = os.path.join(HERE, "build" if not tag else "build_" + tag)
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "lzgpu.h"))
     objs = []
     procs = []

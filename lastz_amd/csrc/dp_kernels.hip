@@ -21,171 +21,12 @@
 #include "lz_host.hpp"
 #include "lz_gapped_host.hpp"
 
-// Cross-lane data movement inside a wave uses DPP (register-to-register, a few cycles) rather than
-// ds_bpermute shuffles (an LDS round trip each): the row sweep is a chain of short dependent steps, so
-// the latency of these exchanges is what a row costs.  The 7-step inclusive scan is the classic GCN
-// sequence: row_shr 1,2,3 (from the original value), row_shr 4 / 8 on the upper banks, then the last
-// lane of rows 0 and 2 broadcast into rows 1 and 3, then lane 31 into rows 2-3.  Lanes a step does not
-// reach receive the operator's identity, so no lane masks are needed (and the order "lower lanes
-// first" is kept for the non-commutative gap-map composition).
-template <int CTRL, int ROWM, int BANKM>
-__device__ __forceinline__ s32 lz_dpp(s32 ident, s32 src) { return __builtin_amdgcn_update_dpp(ident, src, CTRL, ROWM, BANKM, false); }
-#define LZ_GAP_IDENT_A (LZ_DP_NEGINF - (1 << 24))                // f(x) = max(A, x - 0) = x for every score x
-template <int CTRL, int ROWM, int BANKM>
-__device__ __forceinline__ LzDpGap lz_gap_dpp(const LzDpGap& v)
-{
-    LzDpGap t;
-    t.A = lz_dpp<CTRL, ROWM, BANKM>(LZ_GAP_IDENT_A, v.A);
-    t.K = lz_dpp<CTRL, ROWM, BANKM>(0, v.K);
-    t.cut = (u32)lz_dpp<CTRL, ROWM, BANKM>(0, (s32)v.cut);
-    return t;
-}
-#define LZ_WAVE_SCAN(v, x, MOVE, OP)                                   \
-    v = OP(MOVE<0x111, 0xf, 0xf>(x), v);  /* row_shr:1 */               \
-    v = OP(MOVE<0x112, 0xf, 0xf>(x), v);  /* row_shr:2 */               \
-    v = OP(MOVE<0x113, 0xf, 0xf>(x), v);  /* row_shr:3 */               \
-    v = OP(MOVE<0x114, 0xf, 0xe>(v), v);  /* row_shr:4, banks 1-3 */    \
-    v = OP(MOVE<0x118, 0xf, 0xc>(v), v);  /* row_shr:8, banks 2-3 */    \
-    v = OP(MOVE<0x142, 0xa, 0xf>(v), v);  /* row_bcast:15, rows 1,3 */  \
-    v = OP(MOVE<0x143, 0xc, 0xf>(v), v);  /* row_bcast:31, rows 2,3 */
-template <int CTRL, int ROWM, int BANKM>
-__device__ __forceinline__ s32 lz_max_dpp(s32 v) { return lz_dpp<CTRL, ROWM, BANKM>((s32)0x80000000, v); }
-__device__ __forceinline__ s32 lz_smax(s32 a, s32 b) { return a > b ? a : b; }
+#include "dp_kernels_dev.inc"
 
-struct GpuPhases {                      // X for lz_dp_run: one thread = one lane, barrier after each phase
-    LzDpLane regs;
-    template <class F> __device__ __forceinline__ void phase(F&& f) { f((int)threadIdx.x, regs); __syncthreads(); }
-    template <class F> __device__ __forceinline__ void step(F&& f)  { f((int)threadIdx.x, regs); }
-    // The serial steps of the DPs that share a CU must not all land on the same SIMD (the waves of a
-    // workgroup are dealt out over the four SIMDs in order): the leading wave rotates with the block.
-    int lead_wave;
-    s32 cand_wave_max = 0;               // scan_cand -> reduce_row
-    __device__ __forceinline__ int lead_lane() const { return lead_wave << 6; }
-    template <class F> __device__ __forceinline__ void leader(F&& f)
-    {
-        if ((__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave) f();     // a scalar branch: one wave, all its lanes
-        __syncthreads();
-    }
-    // traceback window: lane k of the leading wave holds link k (LzDpLane::tb_v)
-    __device__ __forceinline__ bool in_lead_wave(int lane) const { return (lane >> 6) == lead_wave; }
-    __device__ __forceinline__ u64 tb_ballot_diag() const { const u32 o = regs.tb_v & 3u; return __ballot(o != (u32)LZ_C_FROM_I && o != (u32)LZ_C_FROM_D); }
-    __device__ __forceinline__ u32 tb_link(u32 k) const { return (u32)__builtin_amdgcn_readlane((int)regs.tb_v, __builtin_amdgcn_readfirstlane((int)k)); }
-    template <class F> __device__ __forceinline__ void every_wave(F&& f) { f(); }           // the serial piece on every wave's own copy of the state: no barrier
-    __device__ __forceinline__ bool lead_here() const { return (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 6) == lead_wave; }
-    __device__ __forceinline__ s32 uni(s32 v) { return __builtin_amdgcn_readfirstlane(v); }
-    __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((s32)v); }
-
-    // Cross-lane steps over the workgroup's LZ_DP_LANES lanes: a DPP scan inside each wave, per-wave
-    // partials through LDS, then every lane folds in the partials of the waves below it.
-    __device__ __forceinline__ s32 scan_gap(LzDpSharedBase& sh, s32 x0)
-    {
-        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        const LzDpGap x = { regs.A, regs.K, regs.cut };
-        LzDpGap inc = x;
-        LZ_WAVE_SCAN(inc, x, lz_gap_dpp, lz_dp_gap_compose)
-        const LzDpGap ex = lz_gap_dpp<0x138, 0xf, 0xf>(inc);    // wave_shr:1: exclusive (lane 0: identity)
-        if (wl == 63) sh.wg[w] = inc;
-        __syncthreads();
-        s32 xin = x0;                                            // value entering this wave
-        for (int j = 0; j < w; j++) xin = lz_dp_gap_apply(sh.wg[j], xin);
-        regs.i_in = lz_dp_gap_apply(ex, xin);
-        s32 xend = x0;
-        for (int j = 0; j < LZ_DP_WAVES; j++) xend = lz_dp_gap_apply(sh.wg[j], xend);
-        return xend;                                            // (wg[] is rewritten a row later, barriers in between)
-    }
-    // The same scan for a row without masked cells (BOUNDS == false: cut is 0 in every lane).  Then K of a lane is gapE times
-    // its cells, the running sum of K over the lanes is a closed form -- cum(l) = gapE * min((l + 1) * cpl, width) -- and the
-    // composition of lanes 0..l applied to x0 is  max(x0, max_j (A_j + cum(j))) - cum(l):  ONE prefix maximum instead of
-    // the three-register map scan with its selects (95 -> 35 instructions of a wave that has its SIMD to itself, at five
-    // cycles each).  Same integers as the map algebra: no value comes near the ends of s32.
-    __device__ __forceinline__ s32 scan_gap_plain(LzDpSharedBase& sh, s32 x0, s32 gap_e, u32 cpl, u32 width)
-    {
-        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        // (24-bit multiplies: lanes, cells per lane, widths and the gap-extension penalty are all far below 2^23)
-        const u32 ce = __umul24((u32)lane, cpl), ci = ce + cpl;
-        const s32 cum_incl = __mul24(gap_e, (s32)(ci < width ? ci : width)), cum_excl = __mul24(gap_e, (s32)(ce < width ? ce : width));
-        const s32 x = regs.A + cum_incl;
-        s32 inc = x;
-        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
-        const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
-        // (partials in wg[].A, which the plain scan has to itself -- scan_gap is the other kernel's -- and which is not written again
-        // before the next row's barriers.  NOT wc[]: walk 2 has no barrier, so a fast wave's scan_cand could store its wc[w] before a
-        // slower wave of the workgroup has read this scan's partials from it: ADVICE r4)
-        if (wl == 63) sh.wg[w].A = inc;
-        __syncthreads();
-        s32 pre = x0, all = x0;
-#pragma unroll
-        for (int j = 0; j < LZ_DP_WAVES; j++) { const s32 v = sh.wg[j].A; if (j < w && v > pre) pre = v; if (v > all) all = v; }
-        regs.i_in = (ex > pre ? ex : pre) - cum_excl;
-        return all - __mul24(gap_e, (s32)width);
-    }
-    __device__ __forceinline__ void scan_cand(LzDpSharedBase& sh, s32 b0)
-    {
-        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        const s32 x = regs.cand;
-        s32 inc = x;
-        LZ_WAVE_SCAN(inc, x, lz_max_dpp, lz_smax)
-        const s32 ex = lz_max_dpp<0x138, 0xf, 0xf>(inc);
-        cand_wave_max = __builtin_amdgcn_readlane(inc, 63);     // (reduce_row wants the same maximum: the candidates do not change in walk 3)
-        if (wl == 63) sh.wc[w] = inc;
-        __syncthreads();
-        s32 pre = b0;                                           // (all partials in one read; w is a scalar: selects, no loop)
-#pragma unroll
-        for (int j = 0; j < LZ_DP_WAVES - 1; j++) { const s32 v = sh.wc[j]; if (j < w && v > pre) pre = v; }
-        regs.run_in = ex > pre ? ex : pre;
-    }
-    __device__ __forceinline__ void reduce_row(LzDpSharedBase& sh)
-    {
-        const int lane = (int)threadIdx.x, wl = lane & 63, w = lane >> 6;
-        const u64 has = __ballot(regs.first != 0xFFFFFFFFu);
-        const s32 lo = has ? (s32)__ffsll((long long)has) - 1 : 0, hi = has ? 63 - (s32)__clzll((long long)has) : 0;
-        const u32 first = (u32)__builtin_amdgcn_readlane((s32)regs.first, lo), last = (u32)__builtin_amdgcn_readlane((s32)regs.last, hi);
-        const s32 cmax = cand_wave_max;
-        const u64 att = __ballot(regs.cand == cmax);            // the LAST lane attaining the max owns the column
-        const u32 ccol = (u32)__builtin_amdgcn_readlane((s32)regs.cand_col, 63 - (s32)__clzll((long long)att));
-        if (wl == 0) { sh.whas[w] = has ? 1u : 0u; sh.wfirst[w] = first; sh.wlast[w] = last; sh.wcmax[w] = cmax; sh.wccol[w] = ccol; }
-        __syncthreads();
-    }
-    __device__ __forceinline__ void row_result(const LzDpSharedBase& sh, u32& first, u32& last, s32& cmax, u32& ccol)   // lane 0
-    {
-        u32 f = 0xFFFFFFFFu, l = 0xFFFFFFFFu, cc = 0; s32 cm = LZ_DP_NEGINF - (1 << 24);
-#pragma unroll
-        for (int j = 0; j < LZ_DP_WAVES; j++) {
-            if (sh.whas[j]) { if (f == 0xFFFFFFFFu) f = sh.wfirst[j]; l = sh.wlast[j]; }
-            if (sh.wcmax[j] >= cm) { cm = sh.wcmax[j]; cc = sh.wccol[j]; }
-        }
-        first = f; last = l; cmax = cm; ccol = cc;
-    }
-};
-
-#ifndef LZ_DP_WPE
-#define LZ_DP_WPE 6                    // waves per SIMD the register allocation must allow for the kernel with bounds: six DPs of four waves per CU, what its
-                                       // 25 KiB of LDS hold (round 4 ran five: with the bounds and the active segments walked on the device it needed 87-91
-                                       // registers; reading pieces it takes 57)
-#endif
-#ifndef LZ_DP_WPE_FREE
-#define LZ_DP_WPE_FREE 7               // ... and seven of the problems without earlier alignments (no mask stamps: 22 KiB per DP)
-#endif
-template <bool NOTRIM, bool BOUNDS, bool REPLICATE>
-__global__ void __launch_bounds__(LZ_DP_LANES, BOUNDS ? LZ_DP_WPE : LZ_DP_WPE_FREE)
-k_ydrop(const LzDpProblem* __restrict__ problems, LzDpParams P, const LzDpJob* __restrict__ jobs, const u32* __restrict__ job_ids,
-        const s32* __restrict__ tab_g, LzDpResult* __restrict__ res, u32 tab_rows)
-{
-    // LDS per DP decides how many DPs share a CU (160 KiB): 25.5 KiB of sweep row and state + the rows of the class
-    // table the matrix really has (dynamic: 1 KiB for HOXD70's 8 row classes) = six DPs per CU (round 2: 34 KiB with
-    // a full 32 x 32 table and 32-bit mask stamps, four per CU)
-    __shared__ typename std::conditional<BOUNDS, LzDpShared, LzDpSharedNoMask>::type sh;
-    extern __shared__ __align__(16) s32 tab[];
-    for (u32 k = threadIdx.x; k < tab_rows * LZ_NCLASS; k += LZ_DP_LANES) tab[k] = tab_g[k];
-    __syncthreads();
-    const u32 j = job_ids[blockIdx.x];
-    GpuPhases x;
-    x.lead_wave = (int)((blockIdx.x + (blockIdx.x >> 8)) & (LZ_DP_WAVES - 1));
-    const LzDpJob J = jobs[j];                                  // uniform: lives in scalar registers
-    const LzDpProblem pb = problems[J.problem];                 // (uniform too: the job's problem -- its query, its window of the sequences)
-    P.qdp = pb.qdp; P.qlen = pb.qlen; P.tdp = pb.tdp; P.tlen = pb.tlen;
-    lz_dp_run<NOTRIM, BOUNDS, REPLICATE>(x, sh, P, J, tab, &res[j]);
-}
+// dp_kernels_narrow.hip: the same kernel on two waves per DP with the 16-bit sweep row
+int lzk_ydrop_narrow(bool no_trim, bool bounds, bool repl, unsigned n, size_t dyn_lds, hipStream_t st, const LzDpProblem* problems, const LzDpParams& P,
+                     const LzDpJob* jobs, const u32* job_ids, const s32* tab, LzDpResult* res, u32 tab_rows);
+unsigned lzk_ydrop_narrow_per_cu(bool bounds);
 
 // The same DP with its sweep-row ring in an HBM slot: bands the LDS ring cannot hold (LZ_DP_TOO_WIDE from k_ydrop)
 template <bool NOTRIM, bool BOUNDS>
@@ -247,6 +88,8 @@ struct HipDpExec : LzDpExecutor {
     u64 wide_runs = 0;
     double t_upload = 0, t_kernel = 0, t_ops = 0;               // LZGPU_HOSTPROF: host milliseconds in launch() / fetch_ops()
     u32 tab_rows = LZ_NCLASS;                                  // row classes of the score matrix in use (k_ydrop's dynamic LDS)
+    bool row16_ok = false;                                      // the scoring fits the 16-bit sweep row (lz_dp_row16_ok): the two-wave kernel may be used
+    u64 jobs_narrow = 0;
     const LzDpProblem* problems_dev = nullptr;                  // the launch's problems (run_multi)
     const std::vector<LzDpBatchItem>* cur_items = nullptr;     // ... and their snapshots on the host: what a job's pieces are worked out from
     std::vector<u32> horizon;                                   // per job of the run: rows its pieces are asked for (grows when a sweep passes it)
@@ -323,7 +166,13 @@ struct HipDpExec : LzDpExecutor {
             hipLaunchKernelGGL(wkern, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
-            c.dp_timer.begin("k_ydrop", c.dp_stream);
+            // Which kernel.  Two waves per DP and the 16-bit sweep row (dp_kernels_narrow.hip) whenever the scoring allows it and the launch
+            // is big enough to keep the CUs full with it; four waves per DP and the 32-bit row for the launches of a few DPs, whose time is
+            // the latency of their longest sweep.  LZGPU_DP_NARROW=0 / 1 forces one or the other (tests, A/B).
+            const char* const narrow_env = getenv("LZGPU_DP_NARROW");
+            const bool narrow = row16_ok && (narrow_env ? narrow_env[0] == '1' : n > 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus);
+            if (narrow) jobs_narrow += n;
+            c.dp_timer.begin(narrow ? "k_ydrop_n" : "k_ydrop", c.dp_stream);
             static const size_t pad_lds = []() { const char* e = getenv("LZGPU_DP_PAD_LDS"); return (size_t)(e ? atol(e) : 0); }();   // occupancy experiments: fewer DPs per CU
             const size_t dyn_lds = (size_t)tab_rows * LZ_NCLASS * sizeof(s32) + pad_lds;
             if (!ids_free.empty()) {
@@ -332,6 +181,12 @@ struct HipDpExec : LzDpExecutor {
                 bool repl = n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
                 if (const char* e = getenv("LZGPU_DP_REPL")) repl = e[0] == '1';                 // tests / A-B: force one or the other
                 auto kern = P.no_trim ? (repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>) : (repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
+                if (narrow) {
+                    bool nrepl = n <= 2u * (u64)lzk_ydrop_narrow_per_cu(false) * (u64)c.num_cus;
+                    if (const char* e = getenv("LZGPU_DP_REPL")) nrepl = e[0] == '1';
+                    if ((rc = lzk_ydrop_narrow(P.no_trim != 0, false, nrepl, (unsigned)ids_free.size(), dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(),
+                                               g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows))) return rc;
+                } else
                 hipLaunchKernelGGL(kern, dim3((unsigned)ids_free.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
                                    problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
             }
@@ -339,6 +194,12 @@ struct HipDpExec : LzDpExecutor {
                 bool brepl = n <= 2u * (u64)LZ_DP_WPE * (u64)c.num_cus;             // (the later rounds of a strand: a handful of DPs, each alone on its CU)
                 if (const char* e = getenv("LZGPU_DP_REPL")) brepl = e[0] == '1';
                 auto bkern = P.no_trim ? (brepl ? k_ydrop<true, true, true> : k_ydrop<true, true, false>) : (brepl ? k_ydrop<false, true, true> : k_ydrop<false, true, false>);
+                if (narrow) {
+                    bool nrepl = n <= 2u * (u64)lzk_ydrop_narrow_per_cu(true) * (u64)c.num_cus;
+                    if (const char* e = getenv("LZGPU_DP_REPL")) nrepl = e[0] == '1';
+                    if ((rc = lzk_ydrop_narrow(P.no_trim != 0, true, nrepl, (unsigned)ids_bound.size(), dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(),
+                                               g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows))) return rc;
+                } else
                 hipLaunchKernelGGL(bkern, dim3((unsigned)ids_bound.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
                                    problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
             }
@@ -668,6 +529,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
     ex.P.tb_len = a0.traceback_bytes ? a0.traceback_bytes : 80u * 1024u * 1024u;   // src/lastz.c:395
     ex.slot_tb = g_dp_slot_tb;
     { u32 nr = 0; for (int b = 0; b < 256; b++) if (rowc[b] >= nr) nr = (u32)rowc[b] + 1; ex.tab_rows = nr; }
+    ex.row16_ok = lz_dp_row16_ok(ex.P.ydrop, ex.P.gap_oe, tab, LZ_NCLASS * LZ_NCLASS);
 
     // A bounded pool of host threads works through the problems (a tweener pass hands in tens of thousands of
     // windows at the north star's size: one thread per problem would run into the process's thread limits, and a

@@ -40,7 +40,9 @@
 #endif
 #define LZ_DP_WIDEW   65536           // ... of the wide variant, whose ring lives in HBM (bands the LDS ring cannot hold)
 #define LZ_DP_TBWIN   64              // traceback look-ahead window (links along one diagonal)
-#define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks
+#ifndef LZ_DP_BATCH
+#define LZ_DP_BATCH   2               // cells whose LDS reads are issued together in the walks (and a lane's first cells, carried in registers from walk to walk)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LZ_UNROLL _Pragma("unroll")
 #else
@@ -116,6 +118,18 @@ struct LzDpParams {                     // per batch
 
 struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+void lz_dp_row16_overflow();              // (test harness only: a 16-bit cell out of range)
+#endif
+#define LZ_DP_ROW16_MARGIN 1024
+// may a DP with these parameters keep its sweep row in 16 bits?  (tab: the n score classes x 32 the kernel will index)
+inline bool lz_dp_row16_ok(s32 ydrop, s32 gap_oe, const s32* tab, u32 n)
+{
+    s32 mx = 0;
+    for (u32 k = 0; k < n; k++) if (tab[k] > mx) mx = tab[k];
+    return ydrop >= 0 && gap_oe >= 0 && (s64)ydrop + gap_oe + 1 + LZ_DP_ROW16_MARGIN + mx <= 65535;
+}
+
 // The sweep row is a ring indexed by column & (RING-1).  Two homes for it: arrays in the DP's LDS block (the
 // normal kernel), or a slot in HBM behind pointers (k_ydrop_wide: the rare bands wider than the LDS ring --
 // small gap-extension penalties, huge y-drops; the same code, flat loads instead of ds loads).
@@ -124,24 +138,60 @@ struct LzDpGap { s32 A, K; u32 cut; };       // f(x) = cut ? A : max(A, x - K)
 // DPs per CU): stamp(row) = 1 + (row - 1) mod 65535, never 0 (= no stamp), and the ring's stamps are cleared whenever
 // the stamp wraps to 1 again (lz_dp_run, before the row's own stamps are written), so that a stamp left behind
 // 65535 rows ago cannot be taken for the current row.
-template <u32 W> struct LzDpRingLds {
+// The C / D cells of the ring are reached through four accessors (ld_cd, ld_c, st_cd, st_dead) that take the ring index and the BASE
+// of the row the cell belongs to; the 32-bit rings ignore the base, the 16-bit ones (below) store offsets from it.
+template <u32 W> struct LzDpCells32 {
+    static constexpr bool ROW16 = false;
+    s32 cc[W], dd[W];                     // C[row][col], D[row+1][col]
+    LZ_HD void ld_cd(u32 rx, s32, s32& c, s32& d) const { c = cc[rx]; d = dd[rx]; }
+    LZ_HD s32  ld_c(u32 rx, s32) const { return cc[rx]; }
+    LZ_HD void st_cd(u32 rx, s32, s32 c, s32 d) { cc[rx] = c; dd[rx] = d; }
+    LZ_HD void st_dead(u32 rx) { cc[rx] = LZ_DP_NEGINF; dd[rx] = LZ_DP_NEGINF; }
+    LZ_HD s32& scratch(u32 k) { return cc[k]; }           // (the dead sweep row as 32-bit scratch words, k < W)
+};
+// The 16-bit sweep row (round 5).  Everything a row reads or writes lies in a window below the running best: with
+// F(row) = best(at the start of the row) - yDrop - gapOE - 1,
+//   * a C above F is stored exactly, and so is a D above F;
+//   * a value v <= F can never matter again: a cell with C = v is pruned (v < best - yDrop, :3760), a gap opened from it or extended
+//     from a D / I = v stays <= F, F never falls (best never does), and every comparison that decides a link of a LIVE cell has
+//     C - gapOE >= best - yDrop - gapOE = F + 1 on its other side -- so any two values <= F are interchangeable, negInfinity included;
+//   * no cell of the row exceeds best + (largest substitution score).
+// A cell is therefore kept as a 16-bit offset from base(row) = F(row) - 1024, clamped at 0 from below (0 = "some value <= F":
+// negInfinity, masked and pruned cells), C in the low and D in the high half of one word: one LDS read and one write per cell instead of
+// two, and 12 instead of 20 bytes of LDS per column -- eleven DPs per CU instead of seven.  The launcher takes this kernel only when
+// yDrop + gapOE + 1025 + max(score) <= 65535 (lz_dp_row16_ok); otherwise the 32-bit row.
+template <u32 W> struct LzDpCells16 {
+    static constexpr bool ROW16 = true;
+    u32 cd[W];
+    LZ_HD void ld_cd(u32 rx, s32 base, s32& c, s32& d) const { const u32 v = cd[rx]; c = (s32)(v & 0xFFFFu) + base; d = (s32)(v >> 16) + base; }
+    LZ_HD s32  ld_c(u32 rx, s32 base) const { return (s32)(cd[rx] & 0xFFFFu) + base; }
+    LZ_HD void st_cd(u32 rx, s32 base, s32 c, s32 d)
+    {
+        const s32 a = c > base ? c - base : 0, b = d > base ? d - base : 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (a > 65535 || b > 65535) lz_dp_row16_overflow();      // (test harness: the launcher's rule must make this unreachable)
+#endif
+        cd[rx] = (u32)a | ((u32)b << 16);
+    }
+    LZ_HD void st_dead(u32 rx) { cd[rx] = 0u; }
+    LZ_HD s32& scratch(u32 k) { return reinterpret_cast<s32*>(cd)[k]; }
+};
+template <u32 W, template <u32> class Cells = LzDpCells32> struct LzDpRingLds : Cells<W> {
     static constexpr u32 RING = W;
     static constexpr bool STAMP_WRAPS = true;
     typedef unsigned short stamp_t;
     static LZ_HD u32 stamp(u32 row) { return 1u + (row - 1u) % (u32)LZ_DP_STAMP_PERIOD; }
-    s32 cc[W], dd[W];                     // C[row][col], D[row+1][col]
     stamp_t mk[W];                        // mask stamps
     u8  lk[W];                            // traceback link of the current row
     u8  bb[W];                            // B (query) score classes of the band's columns
 };
 // the ring of a problem without earlier alignments (lz_dp_run<.., BOUNDS = false>): nothing is ever masked, no stamps --
 // 4 KiB less per DP, seven DPs per CU instead of six
-template <u32 W> struct LzDpRingLdsNoMask {
+template <u32 W, template <u32> class Cells = LzDpCells32> struct LzDpRingLdsNoMask : Cells<W> {
     static constexpr u32 RING = W;
     static constexpr bool STAMP_WRAPS = false;
     typedef unsigned short stamp_t;
     static LZ_HD u32 stamp(u32 row) { return row; }
-    s32 cc[W], dd[W];
     stamp_t mk[1];                        // (never touched)
     u8  lk[W];
     u8  bb[W];
@@ -151,7 +201,13 @@ struct LzDpRingHbm {
     static constexpr bool STAMP_WRAPS = false;
     typedef u32 stamp_t;
     static LZ_HD u32 stamp(u32 row) { return row; }
+    static constexpr bool ROW16 = false;
     s32 *cc, *dd; u32* mk; u8 *lk, *bb;
+    LZ_HD void ld_cd(u32 rx, s32, s32& c, s32& d) const { c = cc[rx]; d = dd[rx]; }
+    LZ_HD s32  ld_c(u32 rx, s32) const { return cc[rx]; }
+    LZ_HD void st_cd(u32 rx, s32, s32 c, s32 d) { cc[rx] = c; dd[rx] = d; }
+    LZ_HD void st_dead(u32 rx) { cc[rx] = LZ_DP_NEGINF; dd[rx] = LZ_DP_NEGINF; }
+    LZ_HD s32& scratch(u32 k) { return cc[k]; }
     static constexpr size_t SLOT_BYTES = (size_t)LZ_DP_WIDEW * 14;
     LZ_HD void bind(u8* slot) { cc = (s32*)slot; dd = cc + LZ_DP_WIDEW; mk = (u32*)(dd + LZ_DP_WIDEW); lk = (u8*)(mk + LZ_DP_WIDEW); bb = lk + LZ_DP_WIDEW; }
 };
@@ -176,6 +232,8 @@ struct LzDpSharedBase {
 template <class Ring> struct LzDpSharedT : LzDpSharedBase, Ring {};
 typedef LzDpSharedT<LzDpRingLds<LZ_DP_MAXW>> LzDpShared;
 typedef LzDpSharedT<LzDpRingLdsNoMask<LZ_DP_MAXW>> LzDpSharedNoMask;
+typedef LzDpSharedT<LzDpRingLds<LZ_DP_MAXW, LzDpCells16>> LzDpShared16;
+typedef LzDpSharedT<LzDpRingLdsNoMask<LZ_DP_MAXW, LzDpCells16>> LzDpSharedNoMask16;
 typedef LzDpSharedT<LzDpRingHbm> LzDpSharedWide;
 
 // Sweep state of one DP.  Only lane 0 reads and writes it, so it lives in that lane's registers:
@@ -202,7 +260,7 @@ struct LzDpLane {                       // per-lane values carried between the s
     u32 tb_v;                           // traceback: the link this lane of the leading wave fetched for the window
     // the lane's first LZ_DP_BATCH cells, carried from walk to walk (with two columns per lane -- rows up to 512 wide --
     // that is the whole block: walk 2 and walk 3 then read nothing from the sweep row)
-    s32 k_cc[2], k_dd[2], k_sc[2]; u32 k_mk[2], k_lk[2];
+    s32 k_cc[LZ_DP_BATCH], k_dd[LZ_DP_BATCH], k_sc[LZ_DP_BATCH]; u32 k_mk[LZ_DP_BATCH], k_lk[LZ_DP_BATCH];
 };
 // Cross-lane steps are provided by the executor X (wave shuffles on the GPU, plain loops in the
 // test harness); their semantics are fixed here:
@@ -282,6 +340,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                      const s32* tab /*[32*32] unmasked score classes*/, LzDpResult* res)
 {
     const s32 gapE = P.gap_e, gapOE = P.gap_oe, Y = P.ydrop;
+    const s32 RK = Y + gapOE + 1 + LZ_DP_ROW16_MARGIN;           // 16-bit sweep rows: base(row) = best at the start of the row - RK
     const u32 M = J.M, N = J.N;
     u8*  tb   = P.tb_arena  + J.tb_off;
     u32* trow = P.row_arena + J.row_off;
@@ -344,8 +403,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             sh.aa[lane] = (1 + (u32)lane <= M) ? (u8)(lz_dp_a(P, J, 1 + (u32)lane) & 31u) : 0;      // rows 1..64
             for (u32 col = (u32)lane; col < sh.ry_iter; col += LZ_DP_LANES) {
                 s32 c = (col == 0) ? 0 : -gapOE - (s32)(col - 1) * gapE;
-                sh.cc[LZ_RING(col)] = c;
-                sh.dd[LZ_RING(col)] = c - gapOE;
+                sh.st_cd(LZ_RING(col), -RK, c, c - gapOE);      // (row 0: best = 0)
                 tb[col] = (col == 0) ? 0 : LZ_C_FROM_I;
             }
         });
@@ -401,13 +459,13 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                     const u32 base = RY - np;
                     for (u32 k = 0; k < np; k++) {
                         const s32 iv = i_last - (s32)k * gapE;
-                        sh.cc[LZ_RING(base + k)] = iv; sh.dd[LZ_RING(base + k)] = iv - gapOE;
+                        sh.st_cd(LZ_RING(base + k), best0 - RK, iv, iv - gapOE);     // (cells of the row just swept: its base)
                         if (!REPL || x.lead_here()) tb[(u32)(trow_cur + base + k)] = LZ_C_FROM_I;
                     }
                 } else { p_fill_n = np; p_fill_base = RY - np; p_fill_i = i_last; p_fill_trow = trow_cur; extra = 1; }
                 tb_used += np;
                 if (RY - 1 > ct.max_col) ct.max_col = RY - 1;
-                if ((s32)RY <= NN) { sh.cc[LZ_RING(RY)] = LZ_DP_NEGINF; sh.dd[LZ_RING(RY)] = LZ_DP_NEGINF; RY++; }   // terminating cell, :3818-3826
+                if ((s32)RY <= NN) { sh.st_dead(LZ_RING(RY)); RY++; }   // terminating cell, :3818-3826
                 ct.RY = RY; ct.tb_used = tb_used;
                 // B classes of the columns the next row may reach; every LZ_DP_LANES rows the next block of A classes
                 u32 bh = ct.b_hi;
@@ -464,6 +522,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
         };
         if (REPL) x.every_wave(control); else x.leader(control);
         u32 e_on, mk_lo_now = 0, mk_hi_now = 0;
+        const s32 base_prev = best0 - RK;                        // base of the row just swept (best0 is still that row's)
         if (REPL) {
             finished = x.uni(ct.done) != 0u; e_on = p_extra;
             if (BOUNDS) { mk_lo_now = x.uni(ct.mk_lo); mk_hi_now = x.uni(ct.mk_hi); }
@@ -477,6 +536,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             row = x.uni(v_row); LY0 = x.uni(v_ly); RYi = x.uni(v_ry); cpl = x.uni(v_cpl); best0 = x.uni(v_best); trow_cur = x.uni(v_trow);
         }
         if (finished) break;
+        const s32 base_cur = best0 - RK;                         // ... and of the row about to be
         // the rare parallel pieces of the row set-up: a long run of overhang cells, the next columns' / rows' classes
         if (e_on) {
             const u32 e_fill_n = REPL ? p_fill_n : sh.fill_n, e_fill_base = REPL ? p_fill_base : sh.fill_base, e_fill_trow = REPL ? p_fill_trow : sh.fill_trow;
@@ -485,7 +545,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             x.phase([&](int lane, LzDpLane&) {
                 for (u32 k = (u32)lane; k < e_fill_n; k += LZ_DP_LANES) {
                     const s32 iv = e_fill_i - (s32)k * gapE;
-                    sh.cc[LZ_RING(e_fill_base + k)] = iv; sh.dd[LZ_RING(e_fill_base + k)] = iv - gapOE;
+                    sh.st_cd(LZ_RING(e_fill_base + k), base_prev, iv, iv - gapOE);
                     tb[(u32)(e_fill_trow + e_fill_base + k)] = LZ_C_FROM_I;
                 }
                 for (u32 col = e_stage_lo + (u32)lane; col < e_b_hi; col += LZ_DP_LANES)
@@ -532,7 +592,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             u32 vbb[LZ_DP_BATCH];
             LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                 const u32 rx = LZ_RING(base + k);
-                vcc[k] = sh.cc[rx]; vdd[k] = sh.dd[rx]; if (BOUNDS && any_active) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];   // (any_active is uniform: no stamp is read on a row without a mask piece in reach)
+                sh.ld_cd(rx, base_prev, vcc[k], vdd[k]); if (BOUNDS && any_active) vmk[k] = sh.mk[rx]; else vmk[k] = 0u; vbb[k] = sh.bb[rx];   // (any_active is uniform: no stamp is read on a row without a mask piece in reach)
             }
             LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) vsc[k] = trow_tab[vbb[k] & 31u];
         };
@@ -541,7 +601,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
         x.step([&](int lane, LzDpLane& r) {
             u32 c0 = LY0 + lz_mul24((u32)lane, cpl), c1 = c0 + cpl; if (c1 > RYi) c1 = RYi;
             s32 A = LZ_DP_NEGINF - (1 << 24), K = 0; u32 cut = 0;
-            const s32 cl = sh.cc[LZ_RING(c0 - 1u)];             // (unconditional: issued with the batch's reads; selected below)
+            const s32 cl = sh.ld_c(LZ_RING(c0 - 1u), base_prev);             // (unconditional: issued with the batch's reads; selected below)
             load_batch(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
             r.c_left_old = (c0 < RYi && c0 > LY0) ? cl : LZ_DP_NEGINF;
             s32 c_left = r.c_left_old;
@@ -612,7 +672,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                 }
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
-                    if (col < c1) { const u32 rx = LZ_RING(col); sh.cc[rx] = vcc[k]; sh.dd[rx] = vdd[k]; sh.lk[rx] = (u8)vlk[k]; }
+                    if (col < c1) { const u32 rx = LZ_RING(col); sh.st_cd(rx, base_cur, vcc[k], vdd[k]); sh.lk[rx] = (u8)vlk[k]; }
                 }
             };
             cells(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk, r.k_lk);  // (k_cc / k_lk go on to walk 3)
@@ -650,7 +710,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                                 { r.bnd = c; r.bnd_row = row; r.bnd_col = col; r.bnd_has = 1; }
                             tbr[k] = (u8)link;
                         } else {
-                            sh.cc[LZ_RING(col)] = LZ_DP_NEGINF; sh.dd[LZ_RING(col)] = LZ_DP_NEGINF;
+                            sh.st_dead(LZ_RING(col));
                             tbr[k] = 0;
                         }
                     }
@@ -660,7 +720,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             cells(c0, r.k_cc, r.k_lk);
             for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
                 s32 vcc[LZ_DP_BATCH]; u32 vlk[LZ_DP_BATCH];
-                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) { const u32 rx = LZ_RING(base + k); vcc[k] = sh.cc[rx]; vlk[k] = sh.lk[rx]; }
+                LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) { const u32 rx = LZ_RING(base + k); vcc[k] = sh.ld_c(rx, base_cur); vlk[k] = sh.lk[rx]; }
                 cells(base, vcc, vlk);
             }
             r.first = first; r.last = last;
@@ -682,16 +742,16 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
         // boundaryScore's last update is the last boundary cell attaining the boundary maximum; whichever of the two
         // events came later in row-major order stands (the same cell: the boundary, it is tested second)
         x.phase([&](int lane, LzDpLane& r) {                    // (the sweep row is dead: its first cells carry the lanes' values)
-            sh.cc[lane] = r.bnd_has ? r.bnd : LZ_DP_NEGINF - (1 << 24);
-            sh.cc[LZ_DP_LANES + lane] = (s32)r.bnd_row; sh.cc[2 * LZ_DP_LANES + lane] = (s32)r.bnd_col;
-            sh.dd[lane] = (s32)r.bnd_has;
+            sh.scratch((u32)lane) = r.bnd_has ? r.bnd : LZ_DP_NEGINF - (1 << 24);
+            sh.scratch(LZ_DP_LANES + (u32)lane) = (s32)r.bnd_row; sh.scratch(2 * LZ_DP_LANES + (u32)lane) = (s32)r.bnd_col;
+            sh.scratch(3 * LZ_DP_LANES + (u32)lane) = (s32)r.bnd_has;
         });
         x.phase([&](int lane, LzDpLane&) {
             if (lane != x.lead_lane() || ct.status != LZ_DP_OK) return;
             bool has = false; s32 bc = 0; u32 br = 0, bcol = 0;
             for (int l = 0; l < LZ_DP_LANES; l++) {
-                if (!sh.dd[l]) continue;
-                const s32 c = sh.cc[l]; const u32 rr = (u32)sh.cc[LZ_DP_LANES + l], cl = (u32)sh.cc[2 * LZ_DP_LANES + l];
+                if (!sh.scratch(3 * LZ_DP_LANES + (u32)l)) continue;
+                const s32 c = sh.scratch((u32)l); const u32 rr = (u32)sh.scratch(LZ_DP_LANES + (u32)l), cl = (u32)sh.scratch(2 * LZ_DP_LANES + (u32)l);
                 if (!has || c > bc || (c == bc && (rr > br || (rr == br && cl > bcol)))) { has = true; bc = c; br = rr; bcol = cl; }
             }
             if (has && (br > ct.end1 || (br == ct.end1 && bcol >= ct.end2))) { ct.best = bc; ct.end1 = br; ct.end2 = bcol; }

@@ -63,6 +63,16 @@ u32 emul_verify_pieces(const LzHostSnapshot& S, const LzDpJob& J, u32 horizon, u
 static u64 g_pieces_verified = 0;
 extern "C" u64 emul_gapped_pieces_verified(void) { return g_pieces_verified; }
 
+void lz_dp_row16_overflow() { fprintf(stderr, "emul: a 16-bit sweep-row cell out of range\n"); abort(); }
+static u64 g_row16_runs = 0;
+extern "C" u64 emul_gapped_row16_runs(void) { return g_row16_runs; }
+// one DP through lz_dp_run on the sweep-row type SH, the template switches picked at run time
+template <class SH> static void emul_run_dp(bool bounded, bool no_trim, bool repl, CpuPhases& x, SH& sh, const LzDpParams& P, const LzDpJob& J, const s32* tab, LzDpResult* r)
+{
+    if (bounded) { if (no_trim) (repl ? lz_dp_run<true, true, true, CpuPhases, SH> : lz_dp_run<true, true, false, CpuPhases, SH>)(x, sh, P, J, tab, r); else (repl ? lz_dp_run<false, true, true, CpuPhases, SH> : lz_dp_run<false, true, false, CpuPhases, SH>)(x, sh, P, J, tab, r); }
+    else         { if (no_trim) (repl ? lz_dp_run<true, false, true, CpuPhases, SH> : lz_dp_run<true, false, false, CpuPhases, SH>)(x, sh, P, J, tab, r); else (repl ? lz_dp_run<false, false, true, CpuPhases, SH> : lz_dp_run<false, false, false, CpuPhases, SH>)(x, sh, P, J, tab, r); }
+}
+
 struct EmulExec : LzDpExecutor {
     std::vector<u8> tdp, qdp;           // padded DP-class codes
     u32 tlen, qlen; s32 tab[LZ_NCLASS * LZ_NCLASS];
@@ -72,8 +82,11 @@ struct EmulExec : LzDpExecutor {
     int run(const LzHostSnapshot& snap, std::vector<LzDpJob>& jobs, std::vector<LzDpResult>& res,
             std::vector<std::vector<u32>>& ops) override
     {
-        static LzDpShared sh;
+        static LzDpShared sh; static LzDpShared16 sh16;
         const bool bounded = !snap.aligns.empty();
+        // the 16-bit sweep row wherever the product's rule allows it: EMUL_ROW16=1 for every such DP, =0 for none, default: every other pair of DPs
+        static const int row16_mode = []() { const char* e = getenv("EMUL_ROW16"); return e ? atoi(e) : -1; }();
+        const bool row16_can = lz_dp_row16_ok(ydrop, gap_oe, tab, LZ_NCLASS * LZ_NCLASS);
         static const u32 first_horizon = []() { const char* e = getenv("EMUL_DP_HORIZON"); return (u32)(e ? atoi(e) : 0); }();   // tests: a short one, to run into the re-run
         static const bool verify = getenv("EMUL_VERIFY_PIECES") != nullptr;      // every job's pieces against the reference's row-by-row routines
         for (size_t k = 0; k < jobs.size(); k++) {
@@ -99,8 +112,9 @@ struct EmulExec : LzDpExecutor {
                 J.pc_off = 0; J.n_lb = (u32)pcs.lb.size(); J.n_rb = (u32)pcs.rb.size(); J.n_mk = (u32)pcs.mk.size();
                 J.horizon = pcs.complete ? 0xFFFFFFFFu : horizon;
                 CpuPhases x;
-                if (bounded) { if (no_trim) (k & 1 ? lz_dp_run<true, true, true, CpuPhases, LzDpShared> : lz_dp_run<true, true, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, true, true, CpuPhases, LzDpShared> : lz_dp_run<false, true, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); }
-                else         { if (no_trim) (k & 1 ? lz_dp_run<true, false, true, CpuPhases, LzDpShared> : lz_dp_run<true, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); else (k & 1 ? lz_dp_run<false, false, true, CpuPhases, LzDpShared> : lz_dp_run<false, false, false, CpuPhases, LzDpShared>)(x, sh, P, J, tab, &res[k]); }
+                const bool row16 = row16_can && (row16_mode < 0 ? (k & 2) != 0 : row16_mode != 0);
+                if (row16) { emul_run_dp(bounded, no_trim != 0, (k & 1) != 0, x, sh16, P, J, tab, &res[k]); g_row16_runs++; }
+                else         emul_run_dp(bounded, no_trim != 0, (k & 1) != 0, x, sh, P, J, tab, &res[k]);
                 if (res[k].status == LZ_DP_TOO_WIDE) {              // the product's second kernel: the ring in an HBM slot
                     static std::vector<u8> ring(LzDpRingHbm::SLOT_BYTES);
                     static LzDpSharedWide shw;

@@ -217,3 +217,49 @@ def test_untrimmed_ends_and_all_bounds(L, kw):
     for lo, hi in ((0, 4200), (300, 3300), (1200, 2600)):          # windows of the query: ends inside homologous blocks
         _check(L, t2, q2[lo:hi], **kw)
         _check(L, t2[lo:hi], q2, **kw)
+
+
+def test_sixteen_bit_sweep_row_equals_the_oracle():
+    """Round 5: the C / D cells of the sweep row as 16-bit offsets from a base that follows the running best (LzDpCells16: everything
+    at or below best - yDrop - gapOE - 1 is interchangeable, everything above is kept exactly).  Forced on for every DP the launcher's
+    rule admits (the other tests of this file run every other pair of DPs that way): obstacle course, overlapping alignments, untrimmed
+    ends, all bounds, a small y-drop, and penalties that put the stored offsets at the top of the 16-bit range
+    (yDrop + gapOE + 1025 + 100 = 64,625)."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H, test_emul_gapped as T\n"
+            "lib = C.CDLL(H.build_emul()); lib.emul_gapped_extend.argtypes = T.ARGTYPES; lib.emul_gapped_row16_runs.restype = C.c_uint64\n"
+            "t, q = H.load_case('adversarial')\n"
+            "T._check(lib, t[9000:14500], q[29500:34000])\n"
+            "t, q = H.load_case('synth_overlap')\n"
+            "for kw in (dict(), dict(gap_open=200, gap_extend=60, ydrop=5000), dict(ydrop=700, thresh=2000), dict(no_trim=True), dict(all_bounds=True),\n"
+            "           dict(gap_open=2500, gap_extend=500, ydrop=60500, thresh=2000)):\n"
+            "    n0 = lib.emul_gapped_row16_runs(); st = T._check(lib, t, q, **kw); n1 = lib.emul_gapped_row16_runs()\n"
+            "    assert n1 - n0 >= st['dp_runs'] and st['wide_runs'] == 0, (kw, n0, n1, st)\n"
+            "print('row16', lib.emul_gapped_row16_runs())\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ); env["EMUL_ROW16"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=2400)
+    assert p.returncode == 0 and "row16" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_two_waves_per_dp_and_four_cells_per_batch():
+    """dp_kernels_narrow.hip compiles lz_dp_run with 128 lanes per DP, four cells per batch of LDS reads and the 16-bit sweep row
+    (k_ydrop_n).  The same constants here, lane by lane: obstacle course, overlapping alignments, untrimmed ends, every bound kept,
+    offsets at the top of the 16-bit range."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import helpers as H, test_emul_gapped as T\n"
+            "lib = C.CDLL(H.build_emul(tag='n128', flags=['-DLZ_DP_LANES=128', '-DLZ_DP_BATCH=4'])); lib.emul_gapped_extend.argtypes = T.ARGTYPES\n"
+            "lib.emul_gapped_row16_runs.restype = C.c_uint64\n"
+            "t, q = H.load_case('adversarial')\n"
+            "T._check(lib, t[9000:14500], q[29500:34000])\n"
+            "t, q = H.load_case('synth_overlap')\n"
+            "for kw in (dict(), dict(no_trim=True), dict(all_bounds=True), dict(gap_open=2500, gap_extend=500, ydrop=60500, thresh=2000)):\n"
+            "    T._check(lib, t, q, **kw)\n"
+            "assert lib.emul_gapped_row16_runs() > 700\n"
+            "print('row16', lib.emul_gapped_row16_runs())\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ); env["EMUL_ROW16"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=2400)
+    assert p.returncode == 0 and "row16" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

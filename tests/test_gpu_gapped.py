@@ -257,3 +257,46 @@ def test_both_forms_of_the_row_setup(gpu, repl, no_trim):
     else:
         sub, masked = H.scoring()
         assert mine == T._oracle_blocks_with(t, q)
+
+
+@pytest.mark.parametrize("narrow", ["0", "1"])
+@pytest.mark.parametrize("repl", ["0", "1"])
+def test_both_builds_of_the_dp_kernel(gpu, narrow, repl):
+    """Round 5: k_ydrop (four waves per DP, 32-bit sweep row) and k_ydrop_n (two waves per DP, four cells per batch, the C / D cells of
+    the sweep row as 16-bit offsets from a base that follows the running best: lz_dp_dev.hpp, LzDpCells16).  The launcher picks by the
+    size of a launch; LZGPU_DP_NARROW forces one or the other.  Same alignments from both, with either form of the row set-up: the
+    goldens of the reference (with and without bounds at work: the adversarial piece has 198 alignments bounding each other), untrimmed
+    ends, every bound kept, other penalties and y-drops against the oracle."""
+    import test_oracle_vs_reference as T
+    os.environ["LZGPU_DP_NARROW"] = narrow; os.environ["LZGPU_DP_REPL"] = repl
+    try:
+        gpu.profile_enable(True)
+        for case in ("synth200k", "adversarial"):
+            t, q = H.load_case(case)
+            mine, _ = _gpu_blocks(gpu, t, [q])
+            assert mine == H.lav_blocks(os.path.join(H.GOLDEN, f"{case}.lav")), case
+        t, q = T._option_pairs()["adversarial_piece"]
+        for opt in ("noytrim", "allgappedbounds"):
+            _, okw = T.OPTION_CASES[opt]
+            kw = dict(no_trim=not okw.get("trim_to_peak", True), all_bounds=okw.get("all_bounds", False), score_thresh=okw.get("score_thresh", 3000))
+            mine, _ = _gpu_blocks(gpu, t, [q], **kw)
+            assert mine == H.lav_blocks(os.path.join(H.GOLDEN, f"options_{opt}_adversarial_piece.lav")), opt
+        prof = gpu.profile(); gpu.profile_enable(False)
+        assert prof.get("k_ydrop_n" if narrow == "1" else "k_ydrop", {"launches": 0})["launches"] > 0
+        assert prof.get("k_ydrop" if narrow == "1" else "k_ydrop_n", {"launches": 0})["launches"] == 0
+        # other scorings against the oracle; the last one is outside the 16-bit row's rule (y-drop + gapOE + 1025 + 100 > 65535): the
+        # four-wave kernel runs it whatever LZGPU_DP_NARROW says
+        t, q = H.load_case("synth_overlap")
+        sub, masked = H.scoring()
+        gpu.table_prepare(t, gpu.seed(), CTB)
+        tab = lzo.Table(t, lzo.seed())
+        for kw in (dict(ydrop=3000), dict(gap_open=200, gap_extend=60, ydrop=5000), dict(gap_open=2500, gap_extend=500, ydrop=60500, score_thresh=2000),
+                   dict(gap_open=2500, gap_extend=500, ydrop=64000, score_thresh=2000)):
+            for _, rev, qq in H.strands(q):
+                hsps, _ = lzo.seed_hit_search(tab, qq, masked)
+                segs = lzo.hsps_to_segments(hsps, rev)
+                oal, oops, _ = lzo.gapped_extend(t, qq, sub, lzo.reduce_to_points(t, qq, sub, segs), **kw)
+                al, ops = gpu.gapped_extend(sub, segs.view(lzgpu.SEG_DTYPE), q=qq, **kw)
+                assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all(), kw
+    finally:
+        del os.environ["LZGPU_DP_NARROW"]; del os.environ["LZGPU_DP_REPL"]
