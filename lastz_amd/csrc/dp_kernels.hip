@@ -166,43 +166,37 @@ struct HipDpExec : LzDpExecutor {
             hipLaunchKernelGGL(wkern, dim3((unsigned)n), dim3(LZ_DP_LANES), 0, c.dp_stream,
                                problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), g_dp.rings.as<u8>());
         } else {
-            // Which kernel.  Two waves per DP and the 16-bit sweep row (dp_kernels_narrow.hip) whenever the scoring allows it and the launch
-            // is big enough to keep the CUs full with it; four waves per DP and the 32-bit row for the launches of a few DPs, whose time is
-            // the latency of their longest sweep.  LZGPU_DP_NARROW=0 / 1 forces one or the other (tests, A/B).
+            // Which kernel.  Two waves per DP and the 16-bit sweep row (k_ydrop_n, dp_kernels_narrow.hip) whenever the scoring allows it and
+            // the launch is big enough to keep the CUs full with it: such a launch is bound by the vector instructions it issues, and the
+            // two-wave kernel issues 11 % fewer of them per row.  Four waves per DP and the 32-bit row (k_ydrop) for the launches of a few
+            // DPs, whose time is the latency of their longest sweep (a row of the four-wave kernel takes 3.9 k cycles, of the two-wave
+            // kernel 4.7 k).  LZGPU_DP_NARROW=0 / 1 forces one or the other (tests, A/B).
+            // (Tried and dropped: the DPs expected to sweep the most rows on the four-wave kernel in a second stream beside the two-wave
+            // kernel's launch -- their rows did get faster, the others' slower by as much: profiles/r05_s15_s16_*.)
             const char* const narrow_env = getenv("LZGPU_DP_NARROW");
             const bool narrow = row16_ok && (narrow_env ? narrow_env[0] == '1' : n > 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus);
             if (narrow) jobs_narrow += n;
             c.dp_timer.begin(narrow ? "k_ydrop_n" : "k_ydrop", c.dp_stream);
             static const size_t pad_lds = []() { const char* e = getenv("LZGPU_DP_PAD_LDS"); return (size_t)(e ? atol(e) : 0); }();   // occupancy experiments: fewer DPs per CU
             const size_t dyn_lds = (size_t)tab_rows * LZ_NCLASS * sizeof(s32) + pad_lds;
-            if (!ids_free.empty()) {
-                // (without bounds: every wave its own copy of the row set-up while the launch is about as long as its longest
-                // DP, one leading wave per DP once the CUs stay full -- lz_dp_run's REPL)
-                bool repl = n <= 2u * (u64)LZ_DP_WPE_FREE * (u64)c.num_cus;
-                if (const char* e = getenv("LZGPU_DP_REPL")) repl = e[0] == '1';                 // tests / A-B: force one or the other
-                auto kern = P.no_trim ? (repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>) : (repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>);
-                if (narrow) {
-                    bool nrepl = n <= 2u * (u64)lzk_ydrop_narrow_per_cu(false) * (u64)c.num_cus;
-                    if (const char* e = getenv("LZGPU_DP_REPL")) nrepl = e[0] == '1';
-                    if ((rc = lzk_ydrop_narrow(P.no_trim != 0, false, nrepl, (unsigned)ids_free.size(), dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(),
-                                               g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows))) return rc;
-                } else
-                hipLaunchKernelGGL(kern, dim3((unsigned)ids_free.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
-                                   problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
-            }
-            if (!ids_bound.empty()) {
-                bool brepl = n <= 2u * (u64)LZ_DP_WPE * (u64)c.num_cus;             // (the later rounds of a strand: a handful of DPs, each alone on its CU)
-                if (const char* e = getenv("LZGPU_DP_REPL")) brepl = e[0] == '1';
-                auto bkern = P.no_trim ? (brepl ? k_ydrop<true, true, true> : k_ydrop<true, true, false>) : (brepl ? k_ydrop<false, true, true> : k_ydrop<false, true, false>);
-                if (narrow) {
-                    bool nrepl = n <= 2u * (u64)lzk_ydrop_narrow_per_cu(true) * (u64)c.num_cus;
-                    if (const char* e = getenv("LZGPU_DP_REPL")) nrepl = e[0] == '1';
-                    if ((rc = lzk_ydrop_narrow(P.no_trim != 0, true, nrepl, (unsigned)ids_bound.size(), dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(),
-                                               g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows))) return rc;
-                } else
-                hipLaunchKernelGGL(bkern, dim3((unsigned)ids_bound.size()), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream,
-                                   problems_dev, P, g_dp.jobs.as<LzDpJob>(), g_dp.ids.as<u32>() + ids_free.size(), g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
-            }
+            const char* const repl_env = getenv("LZGPU_DP_REPL");                             // tests / A-B: force one form of the row set-up
+            // one kernel launch: `cnt` DPs of the id list at `first`, with or without bounds
+            // (REPL -- every wave its own copy of the row set-up -- while the DPs of the launch are few enough to be resident together: then its time
+            // is the latency of the longest sweep; one leading wave per DP once the CUs stay full)
+            auto go = [&](bool bounds, size_t first, size_t cnt) -> int {
+                if (!cnt) return 0;
+                const u64 per_cu = narrow ? lzk_ydrop_narrow_per_cu(bounds) : (u64)(bounds ? LZ_DP_WPE : LZ_DP_WPE_FREE);
+                bool repl = n <= 2u * per_cu * (u64)c.num_cus;
+                if (repl_env) repl = repl_env[0] == '1';
+                const u32* idp = g_dp.ids.as<u32>() + first;
+                if (narrow) return lzk_ydrop_narrow(P.no_trim != 0, bounds, repl, (unsigned)cnt, dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(), idp, g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
+                auto kern = bounds ? (P.no_trim ? (repl ? k_ydrop<true, true, true> : k_ydrop<true, true, false>) : (repl ? k_ydrop<false, true, true> : k_ydrop<false, true, false>))
+                                   : (P.no_trim ? (repl ? k_ydrop<true, false, true> : k_ydrop<true, false, false>) : (repl ? k_ydrop<false, false, true> : k_ydrop<false, false, false>));
+                hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(LZ_DP_LANES), dyn_lds, c.dp_stream, problems_dev, P, g_dp.jobs.as<LzDpJob>(), idp, g_dp.tab.as<s32>(), g_dp.res.as<LzDpResult>(), tab_rows);
+                return 0;
+            };
+            if ((rc = go(false, 0, ids_free.size()))) return rc;
+            if ((rc = go(true, ids_free.size(), ids_bound.size()))) return rc;
         }
         c.dp_timer.end(c.dp_stream);
         LZ_HIP(hipGetLastError());
