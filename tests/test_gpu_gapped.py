@@ -270,7 +270,7 @@ def test_both_builds_of_the_dp_kernel(gpu, narrow, repl):
     import test_oracle_vs_reference as T
     os.environ["LZGPU_DP_NARROW"] = narrow; os.environ["LZGPU_DP_REPL"] = repl
     try:
-        gpu.profile_enable(True)
+        gpu.profile_reset(); gpu.profile_enable(True)
         for case in ("synth200k", "adversarial"):
             t, q = H.load_case(case)
             mine, _ = _gpu_blocks(gpu, t, [q])
