@@ -55,7 +55,7 @@ int DevBuf::ensure(size_t bytes)
         want = (want + step - 1) / step * step;
     }
     hipError_t e = hipMalloc(&p, want);
-    if (prof && want >= (64u << 20)) fprintf(stderr, "[lzgpu hostprof] device buffer %zu -> %zu MiB: hipFree %.1f ms, hipMalloc %.1f ms\n", old >> 20, want >> 20,
+    if (prof && want >= (64u << 20)) fprintf(stderr, "[lzgpu hostprof] device buffer %zu -> %zu MiB at %p: hipFree %.1f ms, hipMalloc %.1f ms\n", old >> 20, want >> 20, p,
                                              std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     if (e != hipSuccess) { p = nullptr; return lz_fail(LZGPU_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
     cap = want;

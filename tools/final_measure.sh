@@ -39,3 +39,6 @@ for f in ("bench_multi_path_one_rank_configs3_full", "bench_multi_path_one_rank_
     except Exception as e:
         print(f, "failed", e)
 PY
+# where the host time of the gapped stage goes (this build)
+LZGPU_HOSTPROF=1 LZGPU_DPPROF=1 STEPS=2 BENCH_ARGS=" " bash tools/ab_lib.sh $O/hostprof default 2>&1 | cut -c1-40,240-420 | tee $O/hostprof.txt
+grep "hostprof\] gapped\|dpprof\] launch" $O/hostprof/bench_default.err | head -8 | cut -c1-300 | tee -a $O/hostprof.txt
