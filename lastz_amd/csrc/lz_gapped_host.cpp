@@ -563,11 +563,6 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
         for (; j < n_anchors && fresh.size() < W && entries.size() < scan_limit; j++) {
             const u32 a1 = anchors[j].pos1, a2 = anchors[j].pos2;
             Neighbours nb;
-            if (j + 16 < n_anchors) {                          // (the scan's one cache miss per anchor is its cell of the grid: asked for ahead)
-                const s64 dgp = (s64)anchors[j + 16].pos1 - (s64)anchors[j + 16].pos2;
-                const s64 gp = (dgp >= 0 ? dgp : dgp - (NEAR_DIAG - 1)) / NEAR_DIAG - cell_lo;
-                __builtin_prefetch(&chosen_grid[(size_t)(gp > 0 ? gp - 1 : 0)]); __builtin_prefetch(&chosen_grid[(size_t)gp + 1 < chosen_grid.size() ? (size_t)gp + 1 : chosen_grid.size() - 1]);
-            }
             if (near_align[j] >= 0 && on_alignment(S, S.aligns[near_align[j]], a1, a2)) { cache.erase(j); continue; }
             int ok = msp_left_right(S, a1, a2, nb);
             if (ok < 0) return LZGPU_ERR_STATE;
