@@ -29,6 +29,7 @@
 // candidate bests) -> prefix max -> walk 3 (prune test, stores, traceback bytes) -> row reduction.
 // Lane l owns cpl = ceil(width/LZ_DP_LANES) consecutive columns of the row.
 #pragma once
+#include <type_traits>
 #include "lz_common.hpp"
 
 #ifndef LZ_DP_LANES
@@ -605,11 +606,15 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             load_batch(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
             r.c_left_old = (c0 < RYi && c0 > LY0) ? cl : LZ_DP_NEGINF;
             s32 c_left = r.c_left_old;
-            auto cells = [&](u32 base, const s32* vcc, const s32* vdd, const s32* vsc, const u32* vmk) {
+            // (column LY0 -- no cell to its left, :3697 -- can only be the first cell of the lane whose block starts the row: the test is made for that
+            // cell alone, FIRST = the lane's first batch)
+            const bool at_ly = c0 == LY0;
+            auto cells = [&](auto first_tag, u32 base, const s32* vcc, const s32* vdd, const s32* vsc, const u32* vmk) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
                     if (col < c1) {
-                        const s32 cin = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
+                        const s32 cin = (FIRST && k == 0 && at_ly) ? LZ_DP_NEGINF : c_left + vsc[k];
                         const s32 d = vdd[k];
                         c_left = vcc[k];
                         const bool masked = any_active && vmk[k] == row_stamp;
@@ -623,11 +628,11 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                     }
                 }
             };
-            cells(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
+            cells(std::true_type(), c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk);
             for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
                 s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH];
                 load_batch(base, vcc, vdd, vsc, vmk);
-                cells(base, vcc, vdd, vsc, vmk);
+                cells(std::false_type(), base, vcc, vdd, vsc, vmk);
             }
             r.A = A; r.K = K; r.cut = cut;
         });
@@ -643,28 +648,35 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
             s32 i = r.i_in, c_left = r.c_left_old;
             s32 cmax = LZ_DP_NEGINF - (1 << 24); u32 ccol = 0;
             // one batch: the new C, D and links replace the old values in vcc / vdd / vlk
-            auto cells = [&](u32 base, s32* vcc, s32* vdd, const s32* vsc, const u32* vmk, u32* vlk) {
+            const bool at_ly = c0 == LY0;
+            auto cells = [&](auto first_tag, u32 base, s32* vcc, s32* vdd, const s32* vsc, const u32* vmk, u32* vlk) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
                     vlk[k] = 0;
                     if (col < c1) {
-                        s32 c = (col == LY0) ? LZ_DP_NEGINF : c_left + vsc[k];
+                        s32 c = (FIRST && k == 0 && at_ly) ? LZ_DP_NEGINF : c_left + vsc[k];
                         s32 d = vdd[k];
                         c_left = vcc[k];
                         const bool masked = any_active && vmk[k] == row_stamp;
                         u32 link;
                         if (masked) { link = 0x80; c = LZ_DP_NEGINF; d = LZ_DP_NEGINF; i = LZ_DP_NEGINF; }
-                        else if (d > c || i > c) {
-                            if (d >= i) { c = d; link = LZ_C_FROM_D | LZ_I_EXT | LZ_D_EXT; }
-                            else        { c = i; link = LZ_C_FROM_I | LZ_I_EXT | LZ_D_EXT; }
-                            i -= gapE; d -= gapE;
-                        } else {
-                            if (c >= cmax) { cmax = c; ccol = col; }     // candidate for bestScore (later column wins ties)
-                            const s32 c_open = c - gapOE;
-                            d -= gapE;
-                            if (c_open > d) { d = c_open; link = LZ_C_FROM_C; } else link = LZ_C_FROM_C | LZ_D_EXT;
-                            i -= gapE;
-                            if (c_open > i) i = c_open; else link |= LZ_I_EXT;
+                        else {
+                            // The two cases of :3708-3767 -- a gap wins the cell (d > c || i > c: C = the larger gap, both gaps extend) or the
+                            // diagonal does (candidate best; each gap either opens from C or extends) -- as selects on one instruction stream:
+                            // neighbouring lanes take different cases on most rows, and as two branches each lane paid for both plus the copies
+                            // that merge them.
+                            const s32 m = d > i ? d : i;
+                            const bool gap = m > c, from_d = d >= i;
+                            const s32 dn = d - gapE, in = i - gapE, c_open = c - gapOE;
+                            const bool open_d = !gap && c_open > dn, open_i = !gap && c_open > in;
+                            const bool cand = !gap && c >= cmax;             // candidate for bestScore (later column wins ties)
+                            cmax = cand ? c : cmax; ccol = cand ? col : ccol;
+                            link = gap ? (from_d ? (u32)(LZ_C_FROM_D | LZ_I_EXT | LZ_D_EXT) : (u32)(LZ_C_FROM_I | LZ_I_EXT | LZ_D_EXT))
+                                       : ((open_d ? 0u : (u32)LZ_D_EXT) | (open_i ? 0u : (u32)LZ_I_EXT) | (u32)LZ_C_FROM_C);
+                            c = gap ? m : c;
+                            d = open_d ? c_open : dn;
+                            i = open_i ? c_open : in;
                         }
                         if (i < LZ_DP_NEGINF - (1 << 24)) i = LZ_DP_NEGINF - (1 << 24);
                         vcc[k] = c; vdd[k] = d; vlk[k] = link;
@@ -675,11 +687,11 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                     if (col < c1) { const u32 rx = LZ_RING(col); sh.st_cd(rx, base_cur, vcc[k], vdd[k]); sh.lk[rx] = (u8)vlk[k]; }
                 }
             };
-            cells(c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk, r.k_lk);  // (k_cc / k_lk go on to walk 3)
+            cells(std::true_type(), c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk, r.k_lk);  // (k_cc / k_lk go on to walk 3)
             for (u32 base = c0 + LZ_DP_BATCH; base < c1; base += LZ_DP_BATCH) {
                 s32 vcc[LZ_DP_BATCH], vdd[LZ_DP_BATCH], vsc[LZ_DP_BATCH]; u32 vmk[LZ_DP_BATCH], vlk[LZ_DP_BATCH];
                 load_batch(base, vcc, vdd, vsc, vmk);
-                cells(base, vcc, vdd, vsc, vmk, vlk);
+                cells(std::false_type(), base, vcc, vdd, vsc, vmk, vlk);
             }
             r.cand = cmax; r.cand_col = ccol;
         });
@@ -701,7 +713,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                         const u32 link = vlk[k];
                         const bool live = (link != 0x80) && (c >= rb - Y);
                         if (live) {
-                            if (first == 0xFFFFFFFFu) first = col;
+                            first = first < col ? first : col;      // (columns only grow: the first live one is the least; none yet = 0xFFFFFFFF)
                             last = col;
                             if ((link & 3u) == LZ_C_FROM_C && c > rb) rb = c;
                             // boundaryScore (:3747-3750) never feeds back into the sweep: every lane keeps its own
