@@ -684,7 +684,7 @@ LZ_HD void lz_dp_run(X& x, SH& sh, const LzDpParams& P, const LzDpJob& J,
                 }
                 LZ_UNROLL for (int k = 0; k < LZ_DP_BATCH; k++) {
                     const u32 col = base + k;
-                    if (col < c1) { const u32 rx = LZ_RING(col); sh.st_cd(rx, base_cur, vcc[k], vdd[k]); sh.lk[rx] = (u8)vlk[k]; }
+                    if (col < c1) { const u32 rx = LZ_RING(col); sh.st_cd(rx, base_cur, vcc[k], vdd[k]); if (!FIRST) sh.lk[rx] = (u8)vlk[k]; }   // (walk 3 has the first batch's links in registers)
                 }
             };
             cells(std::true_type(), c0, r.k_cc, r.k_dd, r.k_sc, r.k_mk, r.k_lk);  // (k_cc / k_lk go on to walk 3)
