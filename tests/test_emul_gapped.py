@@ -263,3 +263,26 @@ def test_two_waves_per_dp_and_four_cells_per_batch():
     env = dict(os.environ); env["EMUL_ROW16"] = "1"
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=2400)
     assert p.returncode == 0 and "row16" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_sixteen_bit_sweep_row_under_random_scorings():
+    """The 16-bit row's argument (values at or below best - yDrop - gapOE - 1 are interchangeable) does not depend on the penalties: six
+    scorings drawn at random inside the launcher's rule (gap open 0-2500, extend 1-400, y-drop up to 40,000, threshold 800-4000), the
+    obstacle course (hundreds of alignments bounding and masking each other) against the oracle, every DP on the 16-bit row."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, helpers as H, test_emul_gapped as T\n"
+            "lib = C.CDLL(H.build_emul()); lib.emul_gapped_extend.argtypes = T.ARGTYPES; lib.emul_gapped_row16_runs.restype = C.c_uint64\n"
+            "t, q = H.load_case('adversarial')\n"
+            "rng = np.random.default_rng(20260928)\n"
+            "for k in range(6):\n"
+            "    ge = int(rng.integers(1, 400)); go = int(rng.integers(0, 2500)); yd = int(rng.integers(max(200, 4 * ge), 40000)); th = int(rng.integers(800, 4000))\n"
+            "    rng.integers(0, 9000); rng.integers(0, 9000)\n"
+            "    st = T._check(lib, t[9000:13500], q[29500:33500], gap_open=go, gap_extend=ge, ydrop=yd, thresh=th)\n"
+            "    assert st['wide_runs'] == 0 and st['dp_runs'] > 300, st\n"
+            "assert lib.emul_gapped_row16_runs() > 3000\n"
+            "print('row16', lib.emul_gapped_row16_runs())\n" % (H.ROOT, os.path.join(H.ROOT, "tests")))
+    env = dict(os.environ); env["EMUL_ROW16"] = "1"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=H.ROOT, timeout=2400)
+    assert p.returncode == 0 and "row16" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
