@@ -576,8 +576,9 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
             for (u32 j = 0; j <= k; j++) { free(out[j]); free(ops[j]); out[j] = nullptr; ops[j] = nullptr; n_out[j] = 0; n_ops[j] = 0; }
             return rc;
         }
-    if (hprof) fprintf(stderr, "[lzgpu hostprof] gapped batch of %u: prepare %.2f ms, problems %.2f ms, results %.2f ms; launches: %.2f ms upload, %.2f ms kernel + results back, %.2f ms edit ops back\n",
-                       n, hp_prepared, hp_worked - hp_prepared, hp_ms() - hp_worked, ex.t_upload, ex.t_kernel, ex.t_ops);
+    if (hprof) fprintf(stderr, "[lzgpu hostprof] gapped batch of %u: prepare %.2f ms, problems %.2f ms, results %.2f ms; launches: %.2f ms upload, %.2f ms kernel + results back, %.2f ms edit ops back; %llu of %llu DPs on the two-wave kernel\n",
+                       n, hp_prepared, hp_worked - hp_prepared, hp_ms() - hp_worked, ex.t_upload, ex.t_kernel, ex.t_ops,
+                       (unsigned long long)ex.jobs_narrow, (unsigned long long)(ex.jobs_free + ex.jobs_bounded));
     return 0;
 }
 

@@ -35,7 +35,7 @@ int lzk_ydrop_narrow(bool no_trim, bool bounds, bool repl, unsigned n, size_t dy
     auto kern = bounds ? (no_trim ? (repl ? k_ydrop_n<true, true, true> : k_ydrop_n<true, true, false>) : (repl ? k_ydrop_n<false, true, true> : k_ydrop_n<false, true, false>))
                        : (no_trim ? (repl ? k_ydrop_n<true, false, true> : k_ydrop_n<true, false, false>) : (repl ? k_ydrop_n<false, false, true> : k_ydrop_n<false, false, false>));
     hipLaunchKernelGGL(kern, dim3(n), dim3(LZ_DP_LANES), dyn_lds, st, problems, P, jobs, job_ids, tab, res, tab_rows);
-    return hipGetLastError() == hipSuccess ? 0 : LZGPU_ERR_HIP;
+    return 0;                            // (a launch error is picked up by the caller's hipGetLastError behind the launches of the pass, like the four-wave kernel's)
 }
 // DPs of the narrow kernel a CU holds (the launcher's rule for one leading wave per DP against a copy of the row set-up in every wave)
 unsigned lzk_ydrop_narrow_per_cu(bool bounds) { return bounds ? 8u : 11u; }
