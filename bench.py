@@ -71,6 +71,26 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The driver's contract is ONE JSON line on stdout.  Native libraries write there too (gloo's "[Gloo] Rank 0 is connected ..." went
+    out ahead of the line in round 5): fd 1 is pointed at stderr for the life of the process and emit() writes the line to the
+    descriptor that WAS stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def _kernel_short(name):
     n = name.split("(")[0]
     if "radix_sort" in n or "onesweep" in n or "histogram" in n:
@@ -140,6 +160,21 @@ def pmc_live(child_args, timeout_s=240):
             for k in n:
                 e = out.setdefault(k, {})
                 e[key] = tot[k] / n[k]; e[key + "_total"] = tot[k]; e["launches"] = n[k]
+        # a third pass: wave-instructions issued per kernel (VALU / SALU / LDS), for "instructions per DP row" and "per raw hit";
+        # the byte counters above stand without it
+        od = os.path.join(d, "SQ_INSTS")
+        names = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")
+        cmd = [exe, "--pmc"] + list(names) + ["--kernel-trace", "--output-format", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__), "--pmc-child"] + child_args
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"})
+            for f in glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") in names:
+                        e = out.setdefault(_kernel_short(r["Kernel_Name"]), {})
+                        key = r["Counter_Name"].lower() + "_total"
+                        e[key] = e.get(key, 0.0) + float(r["Counter_Value"])
+        except (subprocess.TimeoutExpired, OSError):
+            pass
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out
@@ -379,6 +414,7 @@ def setup_dist(torch, force_multi=False):
 def bcast_table(torch, dist, lib, rank, local):
     """the three table buffers of rank 0 into the other ranks' allocations (zero copy over RCCL; staged for gloo)"""
     from lastz_amd import shard
+    transport = "rccl" if dist.get_backend() == "nccl" else dist.get_backend() + " (host-staged)"
     for ptr, nbytes in lib.table_buffers():
         if nbytes == 0:
             continue
@@ -396,6 +432,7 @@ def bcast_table(torch, dist, lib, rank, local):
                 torch.cuda.synchronize()
                 lib.device_copy(ptr, stage.data_ptr(), nbytes)
     torch.cuda.synchronize()
+    return transport
 
 
 def hsps_to_segs(lzgpu, hs, ident):
@@ -509,7 +546,7 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
     rec["gapped"] = {"wall_s": gdt, "wall_s_min": min(gdts), "wall_s_calls": gdts, "wall_s_strand_by_strand": sdt,
                      "call": "lzgpu_gapped_extend_batch, both strands as one batch (wall_s: the median of three calls, wall_s_calls); one lzgpu_gapped_extend per strand (wall_s_strand_by_strand)",
                      "anchors": int(len(segs[0]) + len(segs[1])), "alignments": nblocks,
-                     "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"],
+                     "anchors_extended": gc["anchors_extended"], "dp_launched": gc["gapped_extensions"], "dp_rows_launched": gc.get("dp_rows"),
                      "dp_cells_reference": gc["dp_cells"], "gcups_wall": gc["dp_cells"] / gdt / 1e9,
                      "k_ydrop_ms": kms["ms"], "k_ydrop_launches": kms["launches"],
                      "k_ydrop_builds": {k: {"ms": v["ms"], "launches": v["launches"]} for k, v in kparts.items()},
@@ -542,9 +579,21 @@ def attach_traffic(rec, pmc):
         if r.get("traffic"):
             r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
             r["traffic_GBs"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+        e = (pmc or {}).get(r["kernel"]) or {}
+        if e.get("sq_insts_valu_total") and rec["counters_per_step"]["raw_hits"]:
+            # wave-instructions of the dominant kernel per 64 raw hits (one lane per hit): live PMC, the child's one step
+            per = 64.0 / rec["counters_per_step"]["raw_hits"]
+            r["insts_per_64_hits"] = {k: e.get("sq_insts_%s_total" % k, 0.0) * per for k in ("valu", "salu", "lds")}
     g = rec.get("gapped")
     if g:
         es = [(pmc or {}).get(k) for k in ("k_ydrop", "k_ydrop_n")]
+        rows = g.get("dp_rows_launched")
+        iv = sum((x or {}).get("sq_insts_valu_total", 0.0) for x in es)
+        if rows and iv:
+            # VALU / SALU / LDS wave-instructions of the batch's k_ydrop* launches per DP row swept (live PMC: the child's batch = this one)
+            g["valu_per_row"] = iv / rows
+            g["salu_per_row"] = sum((x or {}).get("sq_insts_salu_total", 0.0) for x in es) / rows
+            g["lds_per_row"] = sum((x or {}).get("sq_insts_lds_total", 0.0) for x in es) / rows
         es = [x for x in es if x and "fetch_total" in x and "write_total" in x]
         e = {k: sum(x[k] for x in es) for k in ("fetch_total", "write_total", "launches")} if es else None
         if e:
@@ -783,7 +832,23 @@ def run_single(a, torch, lib):
         out["speedup_vs_cpu_1core"] = rec["value"] / cb["value"] if cb["value"] else None
         if "whole_host" in cb:
             out["speedup_vs_cpu_whole_host"] = rec["value"] / cb["whole_host"]["value"]
-    print(json.dumps(out))
+    # LAST key of the line (the driver stores the tail of it): configs[2]'s DP figures and the north-star pair's headline numbers
+    c2 = {}
+    if gapped is not None:
+        c2.update({"gcups_wall": gapped["gcups_wall"], "k_ydrop_ms": gapped["k_ydrop_ms"], "frac_hbm": gapped["roofline"]["frac"],
+                   "frac_int_alu": gapped["roofline_int_alu"]["frac"], "valu_per_row": gapped.get("valu_per_row"),
+                   "alignments_ok": gapped.get("alignments_ok"), "batch_lav_sha_ok": parity.get("batch_lav_sha_ok")})
+    chain_keys = ("host_s", "device", "device_s", "added_wall_s_beside_a_gapped_batch")
+    if "chain" in rec:
+        c2["chain"] = {k: rec["chain"].get(k) for k in chain_keys}
+    if ns is not None:
+        c2["north_star"] = {"ms_per_step": ns["ms_per_step"], "roofline_frac": ns["roofline"]["frac"], "hsp_sha_ok": ns["parity"]["hsp_sha_ok"],
+                            "gcups_wall": ns["gapped"]["gcups_wall"], "k_ydrop_ms": ns["gapped"]["k_ydrop_ms"],
+                            "valu_per_row": ns["gapped"].get("valu_per_row"),
+                            "chain": {k: ns["chain"].get(k) for k in chain_keys}}
+    c2["seed"] = {"ms_per_step": rec["ms_per_step"], "roofline_frac": rec["roofline"]["frac"], "hsp_sha_ok": parity.get("hsp_sha_ok")}
+    out["configs2"] = c2
+    emit(out)
 
 
 def init_with_selfcheck(torch, dist, lib, world, rank, local):
@@ -877,7 +942,7 @@ def run_multi(a, torch, lib, world, rank, local, dist, selfcheck=None):
         lib.set_bucket_owner(world, rank)
     dev = torch.device("cuda", local)
     use_cuda = dist.get_backend() == "nccl"
-    merged = [None]; aligned = [None]
+    merged = [None]; aligned = [None]; transport = [None]
     phase = {"table_build": 0.0, "table_broadcast": 0.0, "search_and_gapped": 0.0, "gather_merge": 0.0}
     busy = {"search_s": 0.0, "gapped_s": 0.0, "chain_s": 0.0, "dp_cells": 0, "b3_batches": 0}
     timeline = []
@@ -893,7 +958,7 @@ def run_multi(a, torch, lib, world, rank, local, dist, selfcheck=None):
         if rank == 0:
             lib.table_rebuild()
         t = lap("table_build", t)
-        bcast_table(torch, dist, lib, rank, local)
+        transport[0] = bcast_table(torch, dist, lib, rank, local)
         if rank != 0:
             lib.table_commit()
         t = lap("table_broadcast", t)
@@ -1071,6 +1136,10 @@ def run_multi(a, torch, lib, world, rank, local, dist, selfcheck=None):
                "hsps_merged": int(nh), "alignments": al_n, "alignments_sha": al_sha, "chain": bool(a.chain),
                "device_selfcheck": selfcheck, "north_star_unit": ns_check,
                "units_per_rank": [len(p) for p in plan], "bucket_owners": owners,
+               # how the table reached the ranks ("rccl": torch.distributed's nccl backend = RCCL, device buffers in place), and how even the
+               # longest-first deal of the units is: the busiest rank's query bases over the mean (1.0 = perfectly even; the job is as long as that rank)
+               "table_transport": transport[0], "table_bytes": int(sum(nb for _, nb in lib.table_buffers())),
+               "lpt_imbalance": (max(len(p) for p in plan) / (sum(len(p) for p in plan) / float(world))) if sum(len(p) for p in plan) else None,
                # rank 0's clocks of the parts of a step (the table is built and broadcast once per job = once per step)
                "phase_ms_per_step_rank0": {k: v / K * 1e3 for k, v in phase.items()},
                "table_build_and_broadcast_share_of_step": tb / step_s,
@@ -1083,7 +1152,7 @@ def run_multi(a, torch, lib, world, rank, local, dist, selfcheck=None):
                "kernel_ms_per_step_rank0": kern_ms,
                "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt),      # rank 0's launches of the dominant kernel
                "cpu_baseline": cb}
-        print(json.dumps(out))
+        emit(out)
 
 
 def main():
@@ -1126,6 +1195,7 @@ def main():
         pmc_child(a, lib)
         lib.shutdown()
         return
+    claim_stdout()
     import torch                                   # before liblzgpu.so: one HIP runtime per process
     world, rank, local, dist = setup_dist(torch, a.force_multi)
     from lastz_amd import lzgpu

@@ -315,6 +315,8 @@ typedef struct lz_counters {       /* same events as the reference's collect_sta
     uint64_t anchors_extended;
     uint64_t truncated_extensions; /* one-sided DPs that ran out of traceback space (the reference warns
                                       "truncating alignment ...", src/gapped_extend.c:3640-3661)    */
+    uint64_t dp_rows;              /* rows swept by every one-sided DP that ran on the device (speculative re-runs included):
+                                      the denominator of "instructions per DP row" (bench.py, tools/dp_pmc.sh)  */
 } lz_counters;
 void lzgpu_counters_reset(void);
 int  lzgpu_counters_get(lz_counters* out);

@@ -569,6 +569,7 @@ extern "C" int lzgpu_gapped_extend_batch(const lz_gapped_args* args, uint32_t n,
         std::lock_guard<std::mutex> lk(c.counters_m);
         c.counters.anchors_extended += st[k].anchors_extended; c.counters.dp_cells += st[k].dp_cells;
         c.counters.gapped_extensions += st[k].dp_runs; c.counters.truncated_extensions += st[k].truncated;
+        c.counters.dp_rows += st[k].dp_rows;
     }
     for (u32 k = 0; k < n; k++) if (rcs[k]) return rcs[k] < 0 ? lz_fail(rcs[k], "gapped_extend failed (problem %u of the batch)", k) : rcs[k];
     for (u32 k = 0; k < n; k++)

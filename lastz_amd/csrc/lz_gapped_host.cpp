@@ -635,6 +635,7 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
                 cr.rl = res[2 * k]; cr.rr = res[2 * k + 1];
                 cr.ol.swap(ops[2 * k]); cr.orr.swap(ops[2 * k + 1]);
             }
+            for (const LzDpResult& r : res) st.dp_rows += r.max_row;
         }
         st.rounds++; st.dp_runs += jobs.size();
         lap(t_exec);

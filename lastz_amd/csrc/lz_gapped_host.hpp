@@ -49,7 +49,7 @@ struct LzGappedParams {
     u64 max_paired_bases = 0;              // :1441-1459 (0: no limit); exceeded -> LZGPU_NH_PAIRED_LIMIT
 };
 
-struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated; };
+struct LzGappedStats { u64 anchors, anchors_extended, dp_runs, dp_cells, rounds, reruns, truncated, dp_rows; };
 
 // The bounds and the masked cells a job will meet, as pieces of rows complete up to `horizon` (lz_dp_pieces.cpp; LzDpPiece in
 // lz_dp_dev.hpp).  complete: no row beyond the horizon would add a piece (then the pieces hold for any number of rows).

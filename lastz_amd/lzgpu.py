@@ -54,7 +54,8 @@ class WindowSearchArgs(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("words", C.c_uint64), ("raw_hits", C.c_uint64), ("extensions", C.c_uint64),
                 ("bp_extended", C.c_uint64), ("hsps", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("gapped_extensions", C.c_uint64), ("anchors_extended", C.c_uint64), ("truncated_extensions", C.c_uint64)]
+                ("gapped_extensions", C.c_uint64), ("anchors_extended", C.c_uint64), ("truncated_extensions", C.c_uint64),
+                ("dp_rows", C.c_uint64)]
 
 
 HSP_DTYPE = np.dtype([("pos1", "<u4"), ("pos2", "<u4"), ("length", "<u4"), ("score", "<i4")])

@@ -181,6 +181,27 @@ def test_bench_two_ranks_search_and_gapped_stage_equal_one_rank():
     assert two["device_selfcheck"]["ranks_share_a_device"] or two["device_selfcheck"]["devices_visible"] >= 2
 
 
+def test_bench_multi_path_over_rccl_with_one_rank():
+    """bench.py's N > 1 branch on its DEFAULT backend -- torch.distributed "nccl" = RCCL, world = 1 -- so that
+    init_process_group("nccl", device_id=...) and bcast_table's zero-copy RCCL broadcast of the library's own device buffers have run
+    before the driver's 8-GPU node runs them; rank 0's stdout is exactly ONE line (the JSON); same results as the gloo yardstick."""
+    import json, sys
+    env = {k: v for k, v in os.environ.items() if k != "LZ_BENCH_BACKEND"}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    p = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--force-multi"] + SHAPE,
+                       capture_output=True, text=True, env=env, timeout=900, cwd=H.ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out_lines = p.stdout.split("\n")
+    assert len(out_lines) == 2 and out_lines[1] == "" and out_lines[0].startswith("{"), p.stdout[:2000]      # one line, nothing ahead of it
+    rccl = json.loads(out_lines[0])
+    assert rccl["table_transport"] == "rccl" and rccl["table_bytes"] > 64 << 20
+    assert rccl["n_gpus"] == 1 and rccl["lpt_imbalance"] == 1.0 and [r["units"] for r in rccl["per_rank"]] == [6]
+    gloo = _bench(["--gpus", "1", "--force-multi"] + SHAPE, 1, 0)
+    assert gloo["table_transport"].startswith("gloo")
+    assert rccl["hsps_merged"] == gloo["hsps_merged"] > 1000
+    assert rccl["alignments_sha"] == gloo["alignments_sha"] and rccl["alignments"] == gloo["alignments"] > 20
+
+
 def test_bench_chain_in_front_of_the_gapped_stage_on_the_b3_thread():
     """configs[4]'s shape: --chain -- every unit's HSPs chained (lzgpu_reduce_to_chain_batch, host code on the B3 thread beside the next
     unit's search), the chains extended; two ranks = one rank, and the chained job extends fewer anchors into fewer alignments"""
