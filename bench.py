@@ -500,7 +500,8 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
     assert all((a_ == b_).all() for a_, b_ in zip(kept, kept1))
     rec["chain"] = {"call": "lzgpu_reduce_to_chain_batch, both strands side by side (host_s); one lzgpu_reduce_to_chain per strand (host_s_one_after_the_other); default penalties (--chain)",
                     "host_s": c2 - c1, "host_s_one_after_the_other": c1 - c0,
-                    "anchors": int(len(segs[0]) + len(segs[1])), "kept": int(len(kept[0]) + len(kept[1])), "device": "none (host routine)"}
+                    "anchors": int(len(segs[0]) + len(segs[1])), "kept": int(len(kept[0]) + len(kept[1])),
+                    "device": "none (host routine: n dependent steps, each a pruned 2-d tree search of ~0.3 us; DESIGN.md 5 has the estimate of the device alternatives)"}
     # ---- the gapped stage of the same pair (configs[2]: --ydrop=9430)
     probs = lambda: [dict(anchors=segs[slot].copy(), slot=slot, ydrop=9430) for slot in (0, 1)]
     lib.gapped_extend_batch(sub, probs())                                       # warm-up (allocations)
@@ -529,14 +530,20 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
     gpr, gc = lib.profile(), lib.counters()
     lib.profile_enable(False)
     # the chain of another query beside this batch (the N > 1 job's B3 thread does exactly this): wall the chaining ADDS
-    th = threading.Thread(target=lambda: lib.reduce_to_chain_batch(segs))
-    torch.cuda.synchronize()
-    b0 = time.perf_counter()
-    th.start()
-    lib.gapped_extend_batch(sub, probs())
-    th.join()
-    torch.cuda.synchronize()
-    rec["chain"]["added_wall_s_beside_a_gapped_batch"] = max(time.perf_counter() - b0 - gdt, 0.0)
+    # (three samples like wall_s: a single call is at the mercy of whatever else the box does -- round 5's driver line had one 77 ms call among
+    # 61-62 ms ones in wall_s_calls and a single "beside" sample of +23 ms; the figure is median(beside) - median(alone), all samples in the line)
+    bdts = []
+    for _ in range(3):
+        th = threading.Thread(target=lambda: lib.reduce_to_chain_batch(segs))
+        torch.cuda.synchronize()
+        b0 = time.perf_counter()
+        th.start()
+        lib.gapped_extend_batch(sub, probs())
+        th.join()
+        torch.cuda.synchronize()
+        bdts.append(time.perf_counter() - b0)
+    rec["chain"]["added_wall_s_beside_a_gapped_batch"] = max(sorted(bdts)[1] - gdt, 0.0)
+    rec["chain"]["wall_s_calls_beside_a_gapped_batch"] = bdts
     # (the DP kernel has two builds: k_ydrop -- four waves per DP -- and k_ydrop_n -- two waves, 16-bit sweep row --, picked per launch)
     kparts = {k: gpr[k] for k in ("k_ydrop", "k_ydrop_n") if k in gpr}
     kms = {"ms": sum(v["ms"] for v in kparts.values()), "launches": sum(v["launches"] for v in kparts.values())}
