@@ -338,7 +338,20 @@ def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False, whole_host=True):
     return out
 
 
-def seed_roofline(prof, cnt, K, num_probes, dt, pmc=None):
+def gather_ceiling(footprint_bytes):
+    """TB/s of random 64-byte lines this memory system delivers when every CU gathers inside `footprint_bytes` (the access pattern of
+    k_scan_hits' target windows: one random line per raw hit), measured with tools/ub/gather_rate.hip on this hardware and committed as
+    profiles/gather_ceiling.json -- the streaming HBM peak is not reachable by a gather.  -> (GB/s, region MiB, source) or None"""
+    fn = os.path.join(ROOT, "profiles", "gather_ceiling.json")
+    if not os.path.exists(fn):
+        return None
+    c = json.load(open(fn))
+    regs = sorted(c["regions"], key=lambda r: r["mib"])
+    pick = next((r for r in regs if r["mib"] * (1 << 20) >= footprint_bytes), regs[-1])
+    return pick["lines_TBps_pair"] * 1e3, pick["mib"], c["source"]
+
+
+def seed_roofline(prof, cnt, K, num_probes, dt, pmc=None, tlen=None):
     """`roofline` object of the seed stage's dominant kernel from the library's HIP-event timer and work counters.
     Algorithmic bytes per step, SURVEY.md 8(d): B_seed = W*(1+4V) + 8H + 4E + X, split over the kernels that do each
     part: the table probes and chain links (count, fill), the bases the X-drop scans touch (phase A = k_scan_hits),
@@ -354,8 +367,17 @@ def seed_roofline(prof, cnt, K, num_probes, dt, pmc=None):
     launches = prof[dom]["launches"] / K
     avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
     ach = alg[dom] / launches / (avg_ms * 1e-3) / 1e9
+    extra = {}
+    if dom == "k_scan_hits" and tlen:
+        # what the kernel is actually up against (profiles/r06_k_scan_hits_what_bounds_it.txt): one random 64-byte line of the target's
+        # half-overlapping 2-bit blocks (tlen / 2 bytes) per raw hit, against the gather rate the same box reaches on that footprint
+        gc = gather_ceiling(tlen / 2.0)
+        if gc:
+            lines_gbs = 64.0 * Hh / launches / (avg_ms * 1e-3) / 1e9
+            extra = {"gather_lines_GBs": lines_gbs, "gather_ceiling_GBs": gc[0], "gather_ceiling_footprint_mib": gc[1], "gather_ceiling_source": gc[2],
+                     "frac_of_gather_ceiling": lines_gbs / gc[0]}
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, **traffic_fields(dom, pmc, stream_bytes=(8.0 * Hh / launches) if dom == "k_scan_hits" else 0.0),
+            "frac": ach / HBM_PEAK_GBS, **extra, **traffic_fields(dom, pmc, stream_bytes=(8.0 * Hh / launches) if dom == "k_scan_hits" else 0.0),
             "algorithmic_bytes_per_launch": alg[dom] / launches, "avg_launch_ms": avg_ms,
             "launches_per_step": launches,
             # whole seed stage against the same roofline, on wall time
@@ -482,7 +504,7 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
            "hsps": int(len(last[0]) + len(last[1])),
            "counters_per_step": {k: cnt[k] / K for k in ("words", "raw_hits", "extensions", "bp_extended")},
            "kernel_ms_per_step": {k: v["ms"] / K for k, v in prof.items()},
-           "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt)}
+           "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt, tlen=tlen)}
     # k_scan_hits against the same roofline whichever kernel dominates (the content legs: byte-code scans)
     if "k_scan_hits" in prof and prof["k_scan_hits"]["launches"]:
         ms = prof["k_scan_hits"]["ms"] / prof["k_scan_hits"]["launches"]
@@ -849,11 +871,13 @@ def run_single(a, torch, lib):
     if "chain" in rec:
         c2["chain"] = {k: rec["chain"].get(k) for k in chain_keys}
     if ns is not None:
-        c2["north_star"] = {"ms_per_step": ns["ms_per_step"], "roofline_frac": ns["roofline"]["frac"], "hsp_sha_ok": ns["parity"]["hsp_sha_ok"],
+        c2["north_star"] = {"ms_per_step": ns["ms_per_step"], "roofline_frac": ns["roofline"]["frac"], "frac_of_gather_ceiling": ns["roofline"].get("frac_of_gather_ceiling"),
+                            "hsp_sha_ok": ns["parity"]["hsp_sha_ok"],
                             "gcups_wall": ns["gapped"]["gcups_wall"], "k_ydrop_ms": ns["gapped"]["k_ydrop_ms"],
                             "valu_per_row": ns["gapped"].get("valu_per_row"),
                             "chain": {k: ns["chain"].get(k) for k in chain_keys}}
-    c2["seed"] = {"ms_per_step": rec["ms_per_step"], "roofline_frac": rec["roofline"]["frac"], "hsp_sha_ok": parity.get("hsp_sha_ok")}
+    c2["seed"] = {"ms_per_step": rec["ms_per_step"], "roofline_frac": rec["roofline"]["frac"], "frac_of_gather_ceiling": rec["roofline"].get("frac_of_gather_ceiling"),
+                  "hsp_sha_ok": parity.get("hsp_sha_ok")}
     out["configs2"] = c2
     emit(out)
 
@@ -1157,7 +1181,7 @@ def run_multi(a, torch, lib, world, rank, local, dist, selfcheck=None):
                            "rank0_wall_over_sum": per_rank_busy[0]["search_and_gapped_wall_s"] / max(per_rank_busy[0]["search_s"] + per_rank_busy[0]["gapped_s"], 1e-9)},
                "timeline_rank0_last_step": sorted(timeline, key=lambda e: e[2]),
                "kernel_ms_per_step_rank0": kern_ms,
-               "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt),      # rank 0's launches of the dominant kernel
+               "roofline": seed_roofline(prof, cnt, K, sd.num_probes, dt, tlen=tlen),      # rank 0's launches of the dominant kernel
                "cpu_baseline": cb}
         emit(out)
 
