@@ -25,6 +25,9 @@ bash tools/dp_pmc.sh $O/dp_pmc "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST
 # the N > 1 code path of bench.py on this one GPU.  (a) the WHOLE configs[3] job -- 200 Mbp target, 15 queries of 200 Mbp, every unit searched and
 # gapped-extended, unit 0 = the north-star query with its SHA checked in the line: the N = 1 anchor of the curve; (b) configs[4]'s shape (--chain) and
 # the B2-beside-B3 timeline on 50 Mbp units; (c) two ranks over gloo (RCCL refuses two ranks on one device): a smoke run, not a measurement
+# (d, round 6) the same branch on its DEFAULT backend -- torch.distributed "nccl" = RCCL, world 1 -- small shape: init_process_group(nccl, device_id) and the
+# zero-copy broadcast of the table's device buffers have run on this box before the driver's 8-GPU node runs them ("table_transport": "rccl" in the line)
+timeout 600 python bench.py --gpus 1 --force-multi --steps 1 --warmup 0 --tlen-multi 50000000 --q-units 2 --q-unit-len 50000000 --no-cpu-baseline > $O/bench_multi_path_one_rank_rccl.json 2> $O/bench_multi_rccl.err; wc -l $O/bench_multi_path_one_rank_rccl.json; python -c "import json; d=json.load(open('$O/bench_multi_path_one_rank_rccl.json')); print('rccl one rank:', d['table_transport'], d['table_bytes'], 'ms/step', round(d['ms_per_step'],1), 'lpt', d['lpt_imbalance'], [r['units'] for r in d['per_rank']])"
 LZ_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 1 --force-multi --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_multi_path_one_rank_configs3_full.json 2> $O/bench_multi_full.err; tail -c 400 $O/bench_multi_path_one_rank_configs3_full.json; echo
 LZ_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 1 --force-multi --steps 1 --warmup 1 --tlen-multi 50000000 --q-units 2 --q-unit-len 50000000 --no-cpu-baseline > $O/bench_multi_path_one_rank_50m_units.json 2> $O/bench_multi_one.err
 LZ_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 1 --force-multi --chain --steps 1 --warmup 1 --tlen-multi 50000000 --q-units 2 --q-unit-len 50000000 --no-cpu-baseline > $O/bench_multi_path_one_rank_50m_units_chain.json 2>> $O/bench_multi_one.err
