@@ -47,6 +47,7 @@ struct SeqSlot {                    // a sequence resident in HBM
     u32    len = 0;
     bool   have_raw = false;
     uint64_t code_key = 0;          // hash of the (class map, charToBits) the codes were built with
+    uint64_t dp_key = 0;            // hash of the class map the DP codes (dp) were built with; 0 = not built / the bytes changed since
     std::vector<u8> host;           // host copy (entropy post-pass needs the raw bytes)
     u8* raw_base()  const { return raw.as<u8>()  + LZ_SEQ_PAD; }
     u8* code_base() const { return code.as<u8>() + LZ_SEQ_PAD; }

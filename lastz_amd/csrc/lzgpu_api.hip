@@ -258,7 +258,7 @@ static int slot_upload(LzCtx& c, SeqSlot& s, const u8* bytes, u32 len, bool keep
     LZ_HIP(hipMemsetAsync(s.code.p, LZ_CODE_INVALID, total, st));
     if (len) LZ_HIP(hipMemcpyAsync(s.raw_base(), bytes, len, hipMemcpyHostToDevice, st));
     LZ_HIP(hipStreamSynchronize(st));
-    s.len = len; s.have_raw = true; s.code_key = 0;
+    s.len = len; s.have_raw = true; s.code_key = 0; s.dp_key = 0;
     if (keep_host) s.host.assign(bytes, bytes + len); else s.host.clear();
     return 0;
 }
@@ -438,7 +438,7 @@ extern "C" int lzgpu_table_adopt(const lz_table_geom* g)
     if ((rc = c.target.code.ensure(total))) return rc;
     LZ_HIP(hipMemsetAsync(c.target.raw.p, 0, total, c.stream));
     LZ_HIP(hipMemsetAsync(c.target.code.p, LZ_CODE_INVALID, total, c.stream));
-    c.target.len = g->tlen; c.target.have_raw = true; c.target.code_key = 0; c.target.host.clear();
+    c.target.len = g->tlen; c.target.have_raw = true; c.target.code_key = 0; c.target.dp_key = 0; c.target.host.clear();
     if ((rc = c.wstart.ensure(((size_t)(1u << c.seed.weight) + 1) * 4))) return rc;
     if ((rc = c.wpos.ensure((size_t)(g->num_words ? g->num_words : 1) * 4))) return rc;
     LZ_HIP(hipStreamSynchronize(c.stream));
@@ -465,7 +465,7 @@ extern "C" int lzgpu_table_commit(void)
     if (c.target.host.size() != c.geom.tlen) {
         c.target.host.resize(c.geom.tlen);
         if (c.geom.tlen) LZ_HIP(hipMemcpy(c.target.host.data(), c.target.raw_base(), c.geom.tlen, hipMemcpyDeviceToHost));
-        c.target.code_key = 0;
+        c.target.code_key = 0; c.target.dp_key = 0;
     }
     c.have_table = true;
     return 0;
