@@ -270,6 +270,22 @@ def physical_cores():
     return max(len(seen), 1)
 
 
+def cpu_quota():
+    """CPUs' worth of run time the container's cgroup grants this process (cpu.max of cgroup v2, cfs quota / period of v1), or None: a box of the
+    pool shows 256 hardware threads and an affinity mask of all of them, but `1600000 100000` in cpu.max -- sixteen CPUs -- and that, not the
+    128 physical cores, is what "the whole host" can mean for a baseline run there (rounds 3-5 labelled it 128 cores)"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False, whole_host=True):
     """The pristine reference (oracle/_ref/lastz_stats, built from /root/reference in the build container and shipped
     with the snapshot) on a bounded sample of the same workload: 1 core (lastz is single-threaded), then the whole
@@ -307,7 +323,8 @@ def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False, whole_host=True):
         if whole_host:
             # every physical core runs the --nogapped pipeline on its own query sample (consecutive windows of the bench
             # query) against a smaller target sample: the processes share the memory system, which is what bounds them
-            cores = physical_cores()
+            phys, quota = physical_cores(), cpu_quota()
+            cores = phys if quota is None else max(1, min(phys, int(quota + 0.5)))     # one process per CPU this container may actually use
             hs = max(sample_bp // 2, 1000)
             hbp2 = float(hs) * float(hs) * 2.0
             th = os.path.join(d, "th.fa")
@@ -324,7 +341,9 @@ def cpu_baseline(t, q, qlen_bench, sample_bp, gapped=False, whole_host=True):
             hw = time.time() - t0
             rate = cores * hbp2 / hw
             host = {"value": rate / (2.0 * qlen_bench) / 1e9, "unit": "Gbp/s", "cores": cores, "wall_s": round(hw, 2),
-                    "bp2_per_s": rate, "sample": f"{cores} concurrent reference processes (one per physical core), each first {hs} bp of target x "
+                    "host_physical_cores": phys, "cgroup_cpu_quota": quota,
+                    "bp2_per_s": rate, "sample": f"{cores} concurrent reference processes (one per CPU the container's cgroup grants this run: quota {quota}, "
+                                                 f"{phys} physical cores on the host), each first {hs} bp of target x "
                                                  f"its own {hs} bp window of the query, --nogapped, whole-process wall time"}
     rate_bp2 = bp2 / sec
     # seed work is proportional to Tlen*Qlen: the CPU rate in the metric's unit AT THE BENCH WORKLOAD's query size
