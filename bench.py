@@ -559,9 +559,22 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
     # wall_s is the median, the kernel times and counters are the last call's)
     lib.profile_enable(True)
     gdts = []
+    wake = os.environ.get("LZ_BENCH_WAKE", "1") != "0"
+    tick = torch.zeros(1 << 20, device="cuda") if wake else None
+
+    def touch_device():
+        # A GPU that has idled since the previous call (tens of ms of Python between two calls here) answers its first command after 17-35 ms on
+        # this pool (`wall_s_calls` of rounds 5-6: 58-62 ms calls with 77-99 ms ones among them, kernel time identical; LZGPU_HOSTPROF puts the
+        # extra time in the first stream synchronisation of the call).  A pipeline that calls the stage back to back never sees that, so the
+        # timed calls start from a device that has just run something -- LZ_BENCH_WAKE=0 shows the cold figures.
+        if wake:
+            for _ in range(8):
+                tick.add_(1.0)
+        torch.cuda.synchronize()
+
     for _ in range(3):
         lib.profile_reset(); lib.counters_reset(); lib.dp_longest(reset=True)
-        torch.cuda.synchronize()
+        touch_device()
         g0 = time.perf_counter()
         res = lib.gapped_extend_batch(sub, probs())
         torch.cuda.synchronize()
@@ -576,7 +589,7 @@ def measure_pair(torch, lib, lzgpu, target, query, steps, warmup, do_gapped):
     bdts = []
     for _ in range(3):
         th = threading.Thread(target=lambda: lib.reduce_to_chain_batch(segs))
-        torch.cuda.synchronize()
+        touch_device()
         b0 = time.perf_counter()
         th.start()
         lib.gapped_extend_batch(sub, probs())
