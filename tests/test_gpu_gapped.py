@@ -300,3 +300,34 @@ def test_both_builds_of_the_dp_kernel(gpu, narrow, repl):
                 assert len(al) == len(oal) and (al == oal).all() and (ops == oops).all(), kw
     finally:
         del os.environ["LZGPU_DP_NARROW"]; del os.environ["LZGPU_DP_REPL"]
+
+
+def test_dp_codes_follow_the_bytes_of_a_resident_slot(gpu):
+    """Round 6 keeps the DP class codes of a sequence across calls while its bytes and the class map do not change.  A resident query slot that is
+    uploaded again -- same length, other bytes: the two strands of a query -- or extended under another matrix must not see the old codes: every
+    result through the slot equals the result of the same call with a host pointer (which uploads and encodes afresh, and is what the golden /
+    oracle tests above pin)."""
+    sub, masked = H.scoring()
+    t, q = H.load_case("synth_overlap")
+    gpu.table_prepare(t, gpu.seed(), CTB)
+    sub2 = sub.copy(); sub2[ord("A"), ord("C")] = sub2[ord("C"), ord("A")] = -90           # another class map of the same shape
+
+    def segs_of(qq):
+        hsps = gpu.seed_hit_search(masked, q=qq)
+        s = np.zeros(len(hsps), dtype=lzgpu.SEG_DTYPE)
+        s["pos1"] = hsps["pos1"] - hsps["length"]; s["pos2"] = hsps["pos2"] - hsps["length"]; s["length"] = hsps["length"]; s["s"] = hsps["score"]
+        return s
+
+    def same(a, b):
+        return len(a[0]) == len(b[0]) and (a[0] == b[0]).all() and len(a[1]) == len(b[1]) and (np.asarray(a[1]) == np.asarray(b[1])).all()
+
+    n_checked = 0
+    for qq in (q, seqio.revcomp(q), q):                        # slot 5 is overwritten twice with sequences of the same length
+        gpu.query_upload(5, qq)
+        sg = segs_of(qq)
+        for m in (sub, sub2, sub):                             # ... and the class map changes under a resident slot and back
+            via_slot = gpu.gapped_extend(m, sg, slot=5)
+            via_host = gpu.gapped_extend(m, sg, q=qq)
+            assert same(via_slot, via_host)
+            n_checked += len(via_slot[0])
+    assert n_checked > 20
